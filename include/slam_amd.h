@@ -1,0 +1,197 @@
+/*
+ * slam_amd -- C ABI of the MI355X (gfx950) stereo-SLAM front-end kernels.
+ *
+ * Every pointer marked "dev" is a device pointer (e.g. tensor.data_ptr() of a
+ * PyTorch-ROCm tensor); "host" pointers are read on the calling thread before
+ * the call returns.  `stream` is a hipStream_t (0 = the null stream).  Calls
+ * are asynchronous on that stream, allocate no device memory, never
+ * synchronise the device, and never throw: they return SLAM_OK or a negative
+ * code, with a message available from slam_last_error() on the same thread.
+ * The caller owns every buffer.  Calls on distinct streams may overlap.
+ *
+ * "Reference" below is the Python project this library slots under
+ * (TzlilOvadia/SLAM); file:line citations are into that tree.
+ */
+#ifndef SLAM_AMD_H
+#define SLAM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAM_OK 0
+#define SLAM_ERR_BAD_ARG (-1)
+#define SLAM_ERR_LAUNCH (-2)
+#define SLAM_ERR_UNSUPPORTED (-3)
+
+/* Row width of one entry of a segment table (see slam_hamming_match). */
+#define SLAM_SEG_STRIDE 5
+
+/* Largest train-set size of one matching (the packed (distance,index) key keeps
+ * 22 bits for the index).  cv2's BFMatcher itself stops at 2^18 per image. */
+#define SLAM_MAX_TRAIN_ROWS (1 << 22)
+
+/* Upper bound on hypotheses per wavefront batch etc. are internal; limits that
+ * a caller can hit are reported through slam_last_error(). */
+
+int slam_version(void);
+const char *slam_last_error(void);
+
+/*
+ * Repack binary descriptors [n, src_stride] (first desc_bytes bytes of each row
+ * are the descriptor, e.g. 61 for AKAZE, 32 for ORB) into rows of dst_stride
+ * bytes (32 or 64), zero padded.  This is the layout the matcher reads.
+ * Replaces: the numpy descriptor arrays cv2 hands to knnMatch
+ * (models/Matcher.py:116-119) -- no arithmetic, layout only.
+ */
+int slam_pack_descriptors(const uint8_t *src_dev, int n, int desc_bytes,
+                          int src_stride, uint8_t *dst_dev, int dst_stride,
+                          void *stream);
+
+/*
+ * Batched brute-force Hamming k-NN (k = 1 or 2) with the fused match filters.
+ *
+ * Replaces, per batch item:
+ *   cv2.BFMatcher(NORM_HAMMING).knnMatch(q, t, k)  models/Matcher.py:127,140,199,219
+ *   mode 1: Matcher.apply_thresholds ratio test     models/Matcher.py:148-160,178-184
+ *   mode 2: rectified-stereo row filter             utils/utils.py:89-116 (via :302-315)
+ *
+ * seg [batch, 5] int32 dev: per item (q_start, q_count, t_start, t_count,
+ * out_start), all in rows.  Item b matches rows q[q_start .. +q_count) against
+ * rows t[t_start .. +t_count) and writes result rows out_start + local query
+ * index.  q and t may alias (temporal matching within one descriptor table).
+ *
+ * Descriptor rows are stride_bytes (32 or 64) apart, 16-byte aligned; only the
+ * first desc_bytes bytes of a row take part (pad bytes are ignored, they need
+ * not be zero).
+ *
+ * out_idx, out_dist [rows, 2] int32: train index local to the item (0-based
+ * within its t range) and Hamming distance, best first.  Ties go to the lower
+ * train index, and the second entry is the next in (distance, index) order,
+ * exactly as cv2's scan produces.  Missing neighbours (t_count < 2, or k = 1
+ * for column 1) hold idx -1, dist INT32_MAX.
+ *
+ * mode 0: keep_dev may be NULL.
+ * mode 1 (needs k = 2): keep[row] = idx1 >= 0 && (double)d0 < thr * (double)d1.
+ * mode 2: keep[row] = idx0 >= 0 && fabs((double)yq[q_start+i] -
+ *         (double)yt[t_start+idx0]) <= thr; yq/yt are float32 keypoint rows
+ *         indexed like the descriptor rows.
+ *
+ * max_nq / max_nt: upper bounds on q_count / t_count over the batch (the
+ * library cannot read seg without a sync); max_nt <= SLAM_MAX_TRAIN_ROWS.
+ */
+int slam_hamming_match(const uint8_t *q_dev, const uint8_t *t_dev,
+                       const int32_t *seg_dev, int batch, int max_nq,
+                       int max_nt, int desc_bytes, int stride_bytes, int k,
+                       int mode, double thr, const float *yq_dev,
+                       const float *yt_dev, int32_t *out_idx_dev,
+                       int32_t *out_dist_dev, uint8_t *keep_dev, void *stream);
+
+/* The unfiltered form: same as slam_hamming_match(..., mode 0, ...). */
+int slam_hamming_knn2(const uint8_t *q_dev, const uint8_t *t_dev,
+                      const int32_t *seg_dev, int batch, int max_nq, int max_nt,
+                      int desc_bytes, int stride_bytes, int k,
+                      int32_t *out_idx_dev, int32_t *out_dist_dev, void *stream);
+
+/*
+ * Linear (DLT) triangulation of n stereo correspondences.
+ * Replaces: least_squares (utils/utils.py:527-560) as driven per point by
+ * get_3d_points_cloud (utils/utils.py:318-335).
+ *
+ * P, Q: host, 12 doubles each, row-major 3x4 (= k @ m1, k @ m2 at :325).
+ * x1,y1,x2,y2: dev float32 [n] (left / right pixel coordinates).
+ * X,Y,Z: dev float64 [n]; valid: dev u8 [n] = !(Z <= 0 || x1 < x2) (:326-327).
+ * The null vector of the 4x4 system is found by a one-sided Jacobi SVD in
+ * fp64 (agrees with LAPACK to ~1e-12 relative on KITTI geometry).
+ */
+int slam_triangulate_dlt(const double *P_host, const double *Q_host,
+                         const float *x1_dev, const float *y1_dev,
+                         const float *x2_dev, const float *y2_dev, int n,
+                         double *X_dev, double *Y_dev, double *Z_dev,
+                         uint8_t *valid_dev, void *stream);
+
+/*
+ * Triangulation driven by a stereo match table (batched over frames).
+ * Replaces: find_stereo_matches + get_3d_points_cloud for a range of frames
+ * (utils/utils.py:302-335) without the host round trip.
+ *
+ * For item b of seg (the table given to the stereo slam_hamming_match call)
+ * and local left keypoint i with keep[out_start+i] set and j = idx[out_start+i][0]:
+ * triangulate (xq,yq)[q_start+i] with (xt,yt)[t_start+j] into row out_start+i of
+ * X,Y,Z/valid.  Rows without a kept match get valid 0 and NaN coordinates.
+ * stereo_map [rows] int32 (nullable): j for kept rows, -1 otherwise -- the dense
+ * form of array_to_dict(inlier_indices_mapping) (utils/utils.py:156-175).
+ */
+int slam_triangulate_matched(const double *P_host, const double *Q_host,
+                             const float *xq_dev, const float *yq_dev,
+                             const float *xt_dev, const float *yt_dev,
+                             const int32_t *seg_dev, int batch, int max_nq,
+                             const int32_t *idx_dev, const uint8_t *keep_dev,
+                             double *X_dev, double *Y_dev, double *Z_dev,
+                             uint8_t *valid_dev, int32_t *stereo_map_dev,
+                             void *stream);
+
+/*
+ * Four-image consensus join, batched over frame pairs, order preserving.
+ * Replaces: get_matches_that_appear_in_all_4_images (utils/utils.py:338-386)
+ * and find_4_images_matches (models/LoopClosure.py:71-109).
+ *
+ * pair [n_pairs, 6] int32 dev: (prev_row0, prev_count, cur_row0, cur_count,
+ * t_row0, unused) -- prev_row0/cur_row0 are the first rows of the earlier/later
+ * frame in the per-left-keypoint tables (stereo_map, valid3d, X/Y/Z, xL..),
+ * t_row0 the first row of this pair in the temporal match outputs.
+ * For each kept temporal match q -> t (ascending q) with stereo_map[prev q] >= 0,
+ * stereo_map[cur t] >= 0 and valid3d[prev q]: emit one consensus row.
+ *
+ * Outputs, slot = pair * cap + m (m < count[pair] <= cap; the join stops
+ * writing at cap and still counts, so count > cap signals overflow):
+ *   rows [n_pairs*cap, 4] int32 (prev_left, prev_right, cur_left, cur_right)
+ *   cX,cY,cZ f64 : 3-D point of prev_left in the earlier left camera frame
+ *   cuL,cvL f32  : pixel of cur_left in the later left image
+ *   cuR,cvR f32  : pixel of cur_right in the later right image
+ *   count [n_pairs] int32
+ * xR/yR are indexed by right-keypoint rows: r_row0 [n_frames-like] is folded
+ * into pair via cur_r_row0 = pair[...][5].
+ */
+int slam_join_consensus(const int32_t *pair_dev, int n_pairs, int max_nq,
+                        const int32_t *t_idx_dev, const uint8_t *t_keep_dev,
+                        const int32_t *stereo_map_dev,
+                        const uint8_t *valid3d_dev, const double *X_dev,
+                        const double *Y_dev, const double *Z_dev,
+                        const float *xL_dev, const float *yL_dev,
+                        const float *xR_dev, const float *yR_dev, int cap,
+                        int32_t *rows_dev, double *cX_dev, double *cY_dev,
+                        double *cZ_dev, float *cuL_dev, float *cvL_dev,
+                        float *cuR_dev, float *cvR_dev, int32_t *count_dev,
+                        void *stream);
+
+/*
+ * PnP-RANSAC hypothesis scoring: supporters of H candidate poses.
+ * Replaces: find_supporters (utils/utils.py:389-410) as called once per RANSAC
+ * iteration and once after refinement by ransac_for_pnp (utils/utils.py:433,455).
+ *
+ * Rt [n_sets, H, 12] f64 dev (row-major 3x4 per hypothesis); K host 9 doubles;
+ * t_right host 3 doubles (= M2[:,3]).  Point set s occupies slots
+ * [s*cap, s*cap + n_s) of X,Y,Z (f64) and uL,vL,uR,vR (f32), with
+ * n_s = n_dev[s] if n_dev != NULL else n_host (clamped to cap).
+ * counts [n_sets, H] int32; masks (nullable) [n_sets, H, mask_words] u64 with
+ * bit (i & 63) of word (i >> 6) set iff point i supports; mask_words >= ceil(cap/64).
+ * A point supports iff both reprojection distances are < thresh (strict), all
+ * in fp64 with one rounding per operation in the reference's order; no
+ * cheirality test.
+ */
+int slam_score_hypotheses(const double *Rt_dev, int n_sets, int H,
+                          const double *K_host, const double *t_right_host,
+                          const double *X_dev, const double *Y_dev,
+                          const double *Z_dev, const float *uL_dev,
+                          const float *vL_dev, const float *uR_dev,
+                          const float *vR_dev, int cap, const int32_t *n_dev,
+                          int n_host, double thresh, int32_t *counts_dev,
+                          uint64_t *masks_dev, int mask_words, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAM_AMD_H */

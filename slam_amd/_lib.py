@@ -1,0 +1,72 @@
+"""Loader for the in-tree HIP shared library (slam_amd/lib/libslam_amd.so).
+
+The library is the product: there is no CPU fallback.  If it is missing, or a
+call fails, this module raises -- it never routes around the GPU path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libslam_amd.so")
+
+# Every symbol that include/slam_amd.h declares.
+EXPORTS = (
+    "slam_version",
+    "slam_last_error",
+    "slam_pack_descriptors",
+    "slam_hamming_match",
+    "slam_hamming_knn2",
+    "slam_triangulate_dlt",
+    "slam_triangulate_matched",
+    "slam_join_consensus",
+    "slam_score_hypotheses",
+)
+
+
+class SlamError(RuntimeError):
+    """A slam_amd C-ABI call returned a negative status."""
+
+
+_lib = None
+
+
+def load():
+    """dlopen the library once and declare the signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SlamError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C slam_amd/csrc` (there is no CPU fallback)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise SlamError(f"{LIB_PATH} does not export {name}")
+    vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    lib.slam_version.restype = ci
+    lib.slam_version.argtypes = []
+    lib.slam_last_error.restype = ctypes.c_char_p
+    lib.slam_last_error.argtypes = []
+    lib.slam_pack_descriptors.restype = ci
+    lib.slam_pack_descriptors.argtypes = [vp, ci, ci, ci, vp, ci, vp]
+    lib.slam_hamming_match.restype = ci
+    lib.slam_hamming_match.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, vp]
+    lib.slam_hamming_knn2.restype = ci
+    lib.slam_hamming_knn2.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp]
+    lib.slam_triangulate_dlt.restype = ci
+    lib.slam_triangulate_dlt.argtypes = [vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp]
+    lib.slam_triangulate_matched.restype = ci
+    lib.slam_triangulate_matched.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.slam_join_consensus.restype = ci
+    lib.slam_join_consensus.argtypes = [vp, ci, ci] + [vp] * 11 + [ci] + [vp] * 9 + [vp]
+    lib.slam_score_hypotheses.restype = ci
+    lib.slam_score_hypotheses.argtypes = [vp, ci, ci, vp, vp] + [vp] * 7 + [ci, vp, ci, cd, vp, vp, ci, vp]
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().slam_last_error()
+        raise SlamError(f"{what} failed ({status}): {msg.decode() if msg else ''}")

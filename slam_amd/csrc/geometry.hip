@@ -1,0 +1,495 @@
+// DLT triangulation, four-image consensus join and PnP hypothesis scoring (gfx950).
+//
+// All fp64 arithmetic here is compiled with -ffp-contract=off and written in the
+// reference's operation order, one IEEE rounding per operation, so supporter
+// decisions are reproducible bit for bit on any IEEE machine.
+#include "common.h"
+
+namespace slam {
+
+namespace {
+
+struct Mat34 {
+    double m[12];
+};
+struct Mat33 {
+    double m[9];
+};
+struct Vec3 {
+    double v[3];
+};
+
+// ---------------------------------------------------------------------------
+// DLT: null vector of A = [x1*P3-P1; y1*P3-P2; x2*Q3-Q1; y2*Q3-Q2] by one-sided
+// Jacobi on the columns of A (utils/utils.py:527-560 asks LAPACK for vh[-1]).
+// One lane per point; A and V (32 doubles) stay in registers because every
+// index below is a compile-time constant after unrolling.
+constexpr int DLT_MAX_SWEEPS = 30;
+constexpr double DLT_TOL2 = 1e-30;
+
+__device__ __forceinline__ void dlt_point(const Mat34 &P, const Mat34 &Q, double x1, double y1, double x2, double y2,
+                                          double &X, double &Y, double &Z)
+{
+    double a[4][4], v[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        a[0][c] = x1 * P.m[8 + c] - P.m[c];
+        a[1][c] = y1 * P.m[8 + c] - P.m[4 + c];
+        a[2][c] = x2 * Q.m[8 + c] - Q.m[c];
+        a[3][c] = y2 * Q.m[8 + c] - Q.m[4 + c];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            v[r][c] = (r == c) ? 1.0 : 0.0;
+
+    for (int sweep = 0; sweep < DLT_MAX_SWEEPS; ++sweep) {
+        bool rotated = false;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int q = p + 1; q < 4; ++q) {
+                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    alpha += a[r][p] * a[r][p];
+                    beta += a[r][q] * a[r][q];
+                    gamma += a[r][p] * a[r][q];
+                }
+                if (gamma * gamma <= DLT_TOL2 * (alpha * beta))
+                    continue;
+                rotated = true;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                double tt = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                if (zeta < 0.0)
+                    tt = -tt;
+                const double cs = 1.0 / sqrt(1.0 + tt * tt);
+                const double sn = cs * tt;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double ap = a[r][p], aq = a[r][q];
+                    a[r][p] = cs * ap - sn * aq;
+                    a[r][q] = sn * ap + cs * aq;
+                    const double vp = v[r][p], vq = v[r][q];
+                    v[r][p] = cs * vp - sn * vq;
+                    v[r][q] = sn * vp + cs * vq;
+                }
+            }
+        }
+        if (!rotated)
+            break;
+    }
+    double nmin = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        double n2 = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            n2 += a[r][c] * a[r][c];
+        if (c == 0 || n2 < nmin) {
+            nmin = n2;
+            s0 = v[0][c];
+            s1 = v[1][c];
+            s2 = v[2][c];
+            s3 = v[3][c];
+        }
+    }
+    X = s0 / s3;
+    Y = s1 / s3;
+    Z = s2 / s3;
+}
+
+__global__ void __launch_bounds__(256) dlt_kernel(const Mat34 P, const Mat34 Q, const float *__restrict__ x1,
+                                                  const float *__restrict__ y1, const float *__restrict__ x2,
+                                                  const float *__restrict__ y2, int n, double *__restrict__ X,
+                                                  double *__restrict__ Y, double *__restrict__ Z,
+                                                  uint8_t *__restrict__ valid)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float fx1 = x1[i], fx2 = x2[i];
+    double x, y, z;
+    dlt_point(P, Q, (double)fx1, (double)y1[i], (double)fx2, (double)y2[i], x, y, z);
+    X[i] = x;
+    Y[i] = y;
+    Z[i] = z;
+    valid[i] = !(z <= 0.0 || fx1 < fx2);
+}
+
+struct MatchedArgs {
+    const float *xq, *yq, *xt, *yt;
+    const int32_t *seg;
+    int tiles_per_item;
+    const int32_t *idx;
+    const uint8_t *keep;
+    double *X, *Y, *Z;
+    uint8_t *valid;
+    int32_t *stereo_map;
+};
+
+__global__ void __launch_bounds__(256) dlt_matched_kernel(const Mat34 P, const Mat34 Q, const MatchedArgs a)
+{
+    const int item = blockIdx.x / a.tiles_per_item;
+    const int tile = blockIdx.x - item * a.tiles_per_item;
+    const int32_t *seg = a.seg + SLAM_SEG_STRIDE * item;
+    const int qs = seg[0], qn = seg[1], ts = seg[2], os = seg[4];
+    const int i = tile * 256 + threadIdx.x;
+    if (i >= qn)
+        return;
+    const size_t g = (size_t)os + i;
+    int j = -1;
+    if (a.keep[g])
+        j = a.idx[2 * g];
+    double x = __builtin_nan(""), y = x, z = x;
+    bool ok = false;
+    if (j >= 0) {
+        const float fx1 = a.xq[qs + i], fx2 = a.xt[ts + j];
+        dlt_point(P, Q, (double)fx1, (double)a.yq[qs + i], (double)fx2, (double)a.yt[ts + j], x, y, z);
+        ok = !(z <= 0.0 || fx1 < fx2);
+    }
+    a.X[g] = x;
+    a.Y[g] = y;
+    a.Z[g] = z;
+    a.valid[g] = ok;
+    if (a.stereo_map)
+        a.stereo_map[g] = j;
+}
+
+// ---------------------------------------------------------------------------
+// Four-image join: one block per frame pair, order-preserving compaction.
+struct JoinArgs {
+    const int32_t *pair;
+    const int32_t *t_idx;
+    const uint8_t *t_keep;
+    const int32_t *stereo_map;
+    const uint8_t *valid3d;
+    const double *X, *Y, *Z;
+    const float *xL, *yL, *xR, *yR;
+    int cap;
+    int32_t *rows;
+    double *cX, *cY, *cZ;
+    float *cuL, *cvL, *cuR, *cvR;
+    int32_t *count;
+};
+
+__global__ void __launch_bounds__(256) join_kernel(const JoinArgs a)
+{
+    __shared__ int wave_tot[4];
+    const int32_t *pr = a.pair + 6 * blockIdx.x;
+    const int p0 = pr[0], pn = pr[1], c0 = pr[2], cn = pr[3], t0 = pr[4], r0 = pr[5];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int base = 0;
+    for (int q0 = 0; q0 < pn; q0 += 256) {
+        const int q = q0 + tid;
+        bool take = false;
+        int t = -1, pr_right = -1, cr_right = -1;
+        if (q < pn && a.t_keep[t0 + q]) {
+            t = a.t_idx[2 * (size_t)(t0 + q)];
+            if (t >= 0 && t < cn) {
+                pr_right = a.stereo_map[p0 + q];
+                cr_right = a.stereo_map[c0 + t];
+                take = pr_right >= 0 && cr_right >= 0 && a.valid3d[p0 + q];
+            }
+        }
+        const unsigned long long m = __ballot(take);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0)
+            wave_tot[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w)
+            off += wave_tot[w];
+        const int total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        const int slot = off + before;
+        if (take && slot < a.cap) {
+            const size_t o = (size_t)blockIdx.x * a.cap + slot;
+            reinterpret_cast<int4 *>(a.rows)[o] = make_int4(q, pr_right, t, cr_right);
+            a.cX[o] = a.X[p0 + q];
+            a.cY[o] = a.Y[p0 + q];
+            a.cZ[o] = a.Z[p0 + q];
+            a.cuL[o] = a.xL[c0 + t];
+            a.cvL[o] = a.yL[c0 + t];
+            a.cuR[o] = a.xR[r0 + cr_right];
+            a.cvR[o] = a.yR[r0 + cr_right];
+        }
+        base += total;
+        __syncthreads();
+    }
+    if (tid == 0)
+        a.count[blockIdx.x] = base;
+}
+
+// ---------------------------------------------------------------------------
+// Hypothesis scoring (utils/utils.py:389-410): exact fp64 in the written order.
+__device__ __forceinline__ bool supports(const double *__restrict__ rt, const Mat33 &K, const Vec3 &tr, double X,
+                                         double Y, double Z, double uL, double vL, double uR, double vR,
+                                         double thresh)
+{
+    const double L0 = ((rt[0] * X + rt[1] * Y) + rt[2] * Z) + rt[3];
+    const double L1 = ((rt[4] * X + rt[5] * Y) + rt[6] * Z) + rt[7];
+    const double L2 = ((rt[8] * X + rt[9] * Y) + rt[10] * Z) + rt[11];
+    const double R0 = L0 + tr.v[0], R1 = L1 + tr.v[1], R2 = L2 + tr.v[2];
+    const double hl0 = (K.m[0] * L0 + K.m[1] * L1) + K.m[2] * L2;
+    const double hl1 = (K.m[3] * L0 + K.m[4] * L1) + K.m[5] * L2;
+    const double hl2 = (K.m[6] * L0 + K.m[7] * L1) + K.m[8] * L2;
+    const double hr0 = (K.m[0] * R0 + K.m[1] * R1) + K.m[2] * R2;
+    const double hr1 = (K.m[3] * R0 + K.m[4] * R1) + K.m[5] * R2;
+    const double hr2 = (K.m[6] * R0 + K.m[7] * R1) + K.m[8] * R2;
+    const double plx = hl0 / hl2, ply = hl1 / hl2;
+    const double prx = hr0 / hr2, pry = hr1 / hr2;
+    const double dlx = uL - plx, dly = vL - ply;
+    const double drx = uR - prx, dry = vR - pry;
+    const double dl = sqrt(dlx * dlx + dly * dly);
+    const double dr = sqrt(drx * drx + dry * dry);
+    return (dl < thresh) && (dr < thresh);
+}
+
+struct ScoreArgs {
+    const double *Rt;
+    int H;
+    Mat33 K;
+    Vec3 tr;
+    const double *X, *Y, *Z;
+    const float *uL, *vL, *uR, *vR;
+    int cap;
+    const int32_t *n_dev;
+    int n_host;
+    double thresh;
+    int32_t *counts;
+    unsigned long long *masks;
+    int mask_words;
+    int blocks_per_set;
+};
+
+constexpr int SCORE_HPW = 2;  // hypotheses per wavefront (share the point loads)
+
+__global__ void __launch_bounds__(256) score_kernel(const ScoreArgs a)
+{
+    const int set = blockIdx.x / a.blocks_per_set;
+    const int blk = blockIdx.x - set * a.blocks_per_set;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h0 = (blk * 4 + wave) * SCORE_HPW;
+    if (h0 >= a.H)
+        return;
+    int n = a.n_dev ? a.n_dev[set] : a.n_host;
+    n = min(max(n, 0), a.cap);
+    const size_t pbase = (size_t)set * a.cap;
+    double rt[SCORE_HPW][12];
+    bool live[SCORE_HPW];
+#pragma unroll
+    for (int e = 0; e < SCORE_HPW; ++e) {
+        live[e] = (h0 + e) < a.H;
+        const double *src = a.Rt + ((size_t)set * a.H + (live[e] ? h0 + e : h0)) * 12;
+#pragma unroll
+        for (int c = 0; c < 12; ++c)
+            rt[e][c] = src[c];
+    }
+    int cnt[SCORE_HPW];
+#pragma unroll
+    for (int e = 0; e < SCORE_HPW; ++e)
+        cnt[e] = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool in = i < n;
+        const size_t o = pbase + (in ? i : 0);
+        const double X = a.X[o], Y = a.Y[o], Z = a.Z[o];
+        const double uL = (double)a.uL[o], vL = (double)a.vL[o], uR = (double)a.uR[o], vR = (double)a.vR[o];
+#pragma unroll
+        for (int e = 0; e < SCORE_HPW; ++e) {
+            const bool s = in && supports(rt[e], a.K, a.tr, X, Y, Z, uL, vL, uR, vR, a.thresh);
+            const unsigned long long m = __ballot(s);
+            cnt[e] += __popcll(m);
+            if (a.masks && live[e] && lane == 0)
+                a.masks[((size_t)set * a.H + h0 + e) * a.mask_words + (base >> 6)] = m;
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int e = 0; e < SCORE_HPW; ++e)
+            if (live[e])
+                a.counts[(size_t)set * a.H + h0 + e] = cnt[e];
+    }
+}
+
+// Clears mask words that the scoring loop does not reach (words past ceil(n/64)).
+__global__ void __launch_bounds__(256) clear_mask_tail_kernel(unsigned long long *masks, int n_sets, int H,
+                                                              int mask_words, const int32_t *n_dev, int n_host, int cap)
+{
+    const size_t total = (size_t)n_sets * H * mask_words;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int w = (int)(e % mask_words);
+        const int set = (int)(e / ((size_t)H * mask_words));
+        int n = n_dev ? n_dev[set] : n_host;
+        n = min(max(n, 0), cap);
+        if (w >= (n + 63) / 64)
+            masks[e] = 0ull;
+    }
+}
+
+Mat34 load34(const double *p)
+{
+    Mat34 m;
+    for (int i = 0; i < 12; ++i)
+        m.m[i] = p[i];
+    return m;
+}
+
+}  // namespace
+
+}  // namespace slam
+
+using namespace slam;
+
+extern "C" int slam_triangulate_dlt(const double *P, const double *Q, const float *x1, const float *y1,
+                                    const float *x2, const float *y2, int n, double *X, double *Y, double *Z,
+                                    uint8_t *valid, void *stream)
+{
+    if (n < 0)
+        return fail(SLAM_ERR_BAD_ARG, "slam_triangulate_dlt: n = %d", n);
+    if (!P || !Q)
+        return fail(SLAM_ERR_BAD_ARG, "slam_triangulate_dlt: null camera matrix");
+    if (n == 0)
+        return SLAM_OK;
+    if (!x1 || !y1 || !x2 || !y2 || !X || !Y || !Z || !valid)
+        return fail(SLAM_ERR_BAD_ARG, "slam_triangulate_dlt: null buffer");
+    hipLaunchKernelGGL(dlt_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, load34(P), load34(Q), x1,
+                       y1, x2, y2, n, X, Y, Z, valid);
+    return check_launch("slam_triangulate_dlt");
+}
+
+extern "C" int slam_triangulate_matched(const double *P, const double *Q, const float *xq, const float *yq,
+                                        const float *xt, const float *yt, const int32_t *seg, int batch, int max_nq,
+                                        const int32_t *idx, const uint8_t *keep, double *X, double *Y, double *Z,
+                                        uint8_t *valid, int32_t *stereo_map, void *stream)
+{
+    if (batch < 0 || max_nq < 0)
+        return fail(SLAM_ERR_BAD_ARG, "slam_triangulate_matched: negative size");
+    if (!P || !Q)
+        return fail(SLAM_ERR_BAD_ARG, "slam_triangulate_matched: null camera matrix");
+    if (batch == 0 || max_nq == 0)
+        return SLAM_OK;
+    if (!xq || !yq || !xt || !yt || !seg || !idx || !keep || !X || !Y || !Z || !valid)
+        return fail(SLAM_ERR_BAD_ARG, "slam_triangulate_matched: null buffer");
+    MatchedArgs a;
+    a.xq = xq;
+    a.yq = yq;
+    a.xt = xt;
+    a.yt = yt;
+    a.seg = seg;
+    a.tiles_per_item = (max_nq + 255) / 256;
+    a.idx = idx;
+    a.keep = keep;
+    a.X = X;
+    a.Y = Y;
+    a.Z = Z;
+    a.valid = valid;
+    a.stereo_map = stereo_map;
+    const long long blocks = (long long)batch * a.tiles_per_item;
+    if (blocks > 0x7FFFFFFFLL)
+        return fail(SLAM_ERR_BAD_ARG, "slam_triangulate_matched: grid too large");
+    hipLaunchKernelGGL(dlt_matched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, load34(P),
+                       load34(Q), a);
+    return check_launch("slam_triangulate_matched");
+}
+
+extern "C" int slam_join_consensus(const int32_t *pair, int n_pairs, int max_nq, const int32_t *t_idx,
+                                   const uint8_t *t_keep, const int32_t *stereo_map, const uint8_t *valid3d,
+                                   const double *X, const double *Y, const double *Z, const float *xL, const float *yL,
+                                   const float *xR, const float *yR, int cap, int32_t *rows, double *cX, double *cY,
+                                   double *cZ, float *cuL, float *cvL, float *cuR, float *cvR, int32_t *count,
+                                   void *stream)
+{
+    (void)max_nq;
+    if (n_pairs < 0 || cap < 0)
+        return fail(SLAM_ERR_BAD_ARG, "slam_join_consensus: negative size");
+    if (n_pairs == 0)
+        return SLAM_OK;
+    if (!pair || !t_idx || !t_keep || !stereo_map || !valid3d || !X || !Y || !Z || !xL || !yL || !xR || !yR || !rows ||
+        !cX || !cY || !cZ || !cuL || !cvL || !cuR || !cvR || !count)
+        return fail(SLAM_ERR_BAD_ARG, "slam_join_consensus: null buffer");
+    if (reinterpret_cast<uintptr_t>(rows) & 15)
+        return fail(SLAM_ERR_BAD_ARG, "slam_join_consensus: rows must be 16-byte aligned");
+    JoinArgs a;
+    a.pair = pair;
+    a.t_idx = t_idx;
+    a.t_keep = t_keep;
+    a.stereo_map = stereo_map;
+    a.valid3d = valid3d;
+    a.X = X;
+    a.Y = Y;
+    a.Z = Z;
+    a.xL = xL;
+    a.yL = yL;
+    a.xR = xR;
+    a.yR = yR;
+    a.cap = cap;
+    a.rows = rows;
+    a.cX = cX;
+    a.cY = cY;
+    a.cZ = cZ;
+    a.cuL = cuL;
+    a.cvL = cvL;
+    a.cuR = cuR;
+    a.cvR = cvR;
+    a.count = count;
+    hipLaunchKernelGGL(join_kernel, dim3(n_pairs), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("slam_join_consensus");
+}
+
+extern "C" int slam_score_hypotheses(const double *Rt, int n_sets, int H, const double *K, const double *t_right,
+                                     const double *X, const double *Y, const double *Z, const float *uL,
+                                     const float *vL, const float *uR, const float *vR, int cap, const int32_t *n_dev,
+                                     int n_host, double thresh, int32_t *counts, uint64_t *masks, int mask_words,
+                                     void *stream)
+{
+    if (n_sets < 0 || H < 0 || cap < 0)
+        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: negative size");
+    if (!K || !t_right)
+        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: null intrinsics");
+    if (n_sets == 0 || H == 0)
+        return SLAM_OK;
+    if (!Rt || !counts)
+        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: null buffer");
+    if (cap > 0 && (!X || !Y || !Z || !uL || !vL || !uR || !vR))
+        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: null point buffer");
+    if (masks && mask_words < (cap + 63) / 64)
+        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: mask_words %d < ceil(cap/64) = %d", mask_words,
+                    (cap + 63) / 64);
+    ScoreArgs a;
+    a.Rt = Rt;
+    a.H = H;
+    for (int i = 0; i < 9; ++i)
+        a.K.m[i] = K[i];
+    for (int i = 0; i < 3; ++i)
+        a.tr.v[i] = t_right[i];
+    a.X = X;
+    a.Y = Y;
+    a.Z = Z;
+    a.uL = uL;
+    a.vL = vL;
+    a.uR = uR;
+    a.vR = vR;
+    a.cap = cap;
+    a.n_dev = n_dev;
+    a.n_host = n_host;
+    a.thresh = thresh;
+    a.counts = counts;
+    a.masks = reinterpret_cast<unsigned long long *>(masks);
+    a.mask_words = mask_words;
+    a.blocks_per_set = (H + 4 * SCORE_HPW - 1) / (4 * SCORE_HPW);
+    const long long blocks = (long long)n_sets * a.blocks_per_set;
+    if (blocks > 0x7FFFFFFFLL)
+        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    if (masks && mask_words > 0) {
+        const size_t total = (size_t)n_sets * H * mask_words;
+        const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(clear_mask_tail_kernel, dim3(grid), dim3(256), 0, s, a.masks, n_sets, H, mask_words, n_dev,
+                           n_host, cap);
+    }
+    hipLaunchKernelGGL(score_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return check_launch("slam_score_hypotheses");
+}
