@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X stereo-SLAM front-end (matching + triangulation + RANSAC scoring).
+
+One "step" is one pass of the whole front-end over one batch of synthetic KITTI-shaped
+frames already resident in HBM: for P consecutive frame pairs (P+1 frames of N keypoints,
+61-byte descriptors), per pair
+    1 stereo matching (k=1 + row filter), 1 DLT triangulation batch,
+    1 temporal matching (k=2 + ratio test), 1 four-image consensus join,
+    1 supporter count of H seeded pose hypotheses, best-hypothesis selection and
+    inlier-table build.
+The default workload is BASELINE.json configs[1]: consecutive frame pairs at ~2k
+keypoints with a fixed seeded set of 10 000 hypotheses per pair.
+
+    python bench.py --gpus N --steps K --warmup W
+Under torch.distributed.run every rank owns its own contiguous frame range (weak
+scaling: P pairs per GPU) and the per-pair inlier tables are gathered to rank 0 over
+RCCL inside the timed region.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+INT_VALU_PEAK_TOPS = 78.6   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz simple int32 ops (tools/valu_peak.hip)
+HBM_PEAK_GBS = 8000.0
+FP64_VALU_PEAK_TF = 78.6
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=128, help="frame pairs per GPU per step")
+    ap.add_argument("--kp", type=int, default=2000, help="keypoints per image")
+    ap.add_argument("--hyp", type=int, default=10000, help="pose hypotheses per pair")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=2, help="frame pairs timed on the CPU oracle")
+    return ap.parse_args()
+
+
+def cpu_baseline(seq, Rt_host, n_pairs, threads):
+    """Time the C oracle (oracle/slam_oracle.c) on the first n_pairs pairs of the same
+    workload, on this host's cores.  Checker code timed as a baseline; never shipped."""
+    from oracle import cpu as oracle
+    from slam_amd.synthetic import read_cameras
+    k, m1, m2 = read_cameras()
+    P, Q = k @ m1, k @ m2
+    F = seq.frames
+    t0 = time.perf_counter()
+    prev = None
+    for f in range(n_pairs + 1):
+        fr = F[f]
+        idx, _ = oracle.hamming_knn(fr.descL, fr.descR, 1, threads=threads)
+        keep = oracle.row_filter(idx, fr.kpL[:, 1], fr.kpR[:, 1], 2.0)
+        j = np.where(keep > 0, idx[:, 0], 0)
+        X, Y, Z, valid = oracle.triangulate_dlt(P, Q, fr.kpL[:, 0], fr.kpL[:, 1], fr.kpR[j, 0], fr.kpR[j, 1],
+                                                threads=threads)
+        smap = np.where(keep > 0, idx[:, 0], -1).astype(np.int32)
+        valid = (valid * (keep > 0)).astype(np.uint8)
+        cur = (smap, X, Y, Z, valid)
+        if prev is not None:
+            pf = F[f - 1]
+            tidx, tdist = oracle.hamming_knn(pf.descL, fr.descL, 2, threads=threads)
+            tkeep = oracle.ratio_filter(tidx, tdist, 1.0)
+            rows = oracle.join(tidx, tkeep, prev[0], prev[4], cur[0])
+            oracle.score_hypotheses(Rt_host[f - 1], k, m2[:, 3], prev[1][rows[:, 0]], prev[2][rows[:, 0]],
+                                    prev[3][rows[:, 0]], fr.kpL[rows[:, 2], 0], fr.kpL[rows[:, 2], 1],
+                                    fr.kpR[rows[:, 3], 0], fr.kpR[rows[:, 3], 1], 2.0, want_masks=True,
+                                    threads=threads)
+        prev = cur
+    dt = time.perf_counter() - t0
+    return n_pairs / dt, dt
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from slam_amd import pipeline, sharding
+    from slam_amd.synthetic import SyntheticSequence, read_cameras, seeded_hypotheses
+
+    # ---- synthetic shard of this rank ---------------------------------------
+    P, N, H = a.pairs, a.kp, a.hyp
+    seq = SyntheticSequence(N, P + 1, seed=6 + 100003 * rank)
+    Rt_host = np.stack([seeded_hypotheses(seq.relative_pose(p, p + 1), H, seed=6 + p) for p in range(P)])
+    k, m1, m2 = read_cameras()
+    fe = pipeline.FrontEnd(k, m1, m2, row_thresh=2.0, ratio_thresh=1.0, pix_thresh=2.0)
+    tb = pipeline.FrameTables.from_frames(seq.frames, dev)
+    ws = fe.prepare(tb, n_hyp=H, want_masks=False)
+    Rt = torch.from_numpy(Rt_host).to(dev)
+    gather = sharding.TableGather(ws, world, rank) if world > 1 else None
+
+    def step():
+        fe.run(ws, Rt)
+        if gather is not None:
+            gather.run()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- per-stage device time (HIP events on the launch stream), after the timed region
+    names = ["stereo_match", "triangulate", "temporal_match", "join", "score", "select"]
+    stage_ms = {n: 0.0 for n in names}
+    reps = 5
+    import ctypes
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(reps):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
+        ev[0].record()
+        fe.stereo_match(ws, stream); ev[1].record()
+        fe.triangulate(ws, stream); ev[2].record()
+        fe.temporal_match(ws, stream); ev[3].record()
+        fe.join(ws, stream); ev[4].record()
+        fe.score(ws, Rt, stream); ev[5].record()
+        fe.select(ws, Rt, stream); ev[6].record()
+        torch.cuda.synchronize()
+        for i, n in enumerate(names):
+            stage_ms[n] += ev[i].elapsed_time(ev[i + 1]) / reps
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- algorithmic work of one step on one GPU ------------------------------
+    nL = np.diff(tb.offL).astype(np.float64)
+    nR = np.diff(tb.offR).astype(np.float64)
+    words = tb.descL.shape[1] // 4
+    pairs_stereo = float((nL * nR).sum())
+    pairs_temporal = float((nL[:-1] * nL[1:]).sum())
+    match_ops = 2.0 * words * (pairs_stereo + pairs_temporal)          # 1 xor + 1 popcount-accumulate per word
+    match_ms = stage_ms["stereo_match"] + stage_ms["temporal_match"]
+    achieved = match_ops / (match_ms * 1e-3) / 1e12
+    n_cons = ws.cons.count.cpu().numpy()[:P].astype(np.float64)
+    n_tri = float(ws.s_keep.sum().item())
+    tri_bytes = 41.0 * n_tri
+    score_evals = float((n_cons * H).sum())
+    score_bytes = float((100.0 * H + 40.0 * n_cons + 8.0 * H * np.ceil(n_cons / 64)).sum())
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hamming_knn_kernel_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "stereo frame-pairs/sec (match+triangulate+RANSAC)",
+        "value": world * P * a.steps / dt,
+        "unit": "frame-pairs/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / a.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32 popcount (matching) + f64 (triangulation, scoring)",
+        "data": "synthetic",
+        "config": {"workload": "configs[1]: consecutive frame pairs, 4-way match + PnP-RANSAC scoring of a fixed "
+                               "seeded hypothesis set", "pairs_per_gpu_per_step": P, "keypoints_per_image": N,
+                   "descriptor_bytes": tb.desc_bytes, "hypotheses_per_pair": H,
+                   "mean_consensus_matches": float(n_cons.mean()), "sharding": f"frame-range x{world}"},
+        "roofline": {"kernel": "hamming_knn_kernel (2 launches per step)", "bound": "valu",
+                     "achieved": achieved, "peak": INT_VALU_PEAK_TOPS, "unit": "Tint32-op/s",
+                     "frac": achieved / INT_VALU_PEAK_TOPS, "traffic": traffic,
+                     "avg_launch_ms": match_ms / 2.0,
+                     "algorithmic": f"{2 * words} int32 ops per descriptor pair x {pairs_stereo + pairs_temporal:.4g} "
+                                    f"pairs per step"},
+        "stages_ms": stage_ms,
+        "stage_rooflines": {
+            "triangulate": {"bound": "hbm", "achieved": tri_bytes / (stage_ms["triangulate"] * 1e-3) / 1e9,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": tri_bytes / (stage_ms["triangulate"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "points": n_tri},
+            "score": {"bound": "fp64-valu", "achieved": 72.0 * score_evals / (stage_ms["score"] * 1e-3) / 1e12,
+                      "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                      "frac": 72.0 * score_evals / (stage_ms["score"] * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
+                      "hbm_GBs": score_bytes / (stage_ms["score"] * 1e-3) / 1e9, "evaluations": score_evals},
+        },
+    }
+    if not a.no_cpu_baseline:
+        threads = min(16, os.cpu_count() or 1)
+        n_cpu = max(1, min(a.cpu_pairs, P))
+        v, secs = cpu_baseline(seq, Rt_host, n_cpu, threads)
+        out["cpu_baseline"] = {"value": v, "unit": "frame-pairs/s", "cores": threads, "kind": "port",
+                               "sample": f"first {n_cpu} frame pairs of the same batch ({N} kp, {H} hypotheses), "
+                                         f"C oracle with OpenMP over queries/points/hypotheses, {secs:.1f} s"}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

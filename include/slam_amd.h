@@ -28,13 +28,12 @@ extern "C" {
 
 /* Row width of one entry of a segment table (see slam_hamming_match). */
 #define SLAM_SEG_STRIDE 5
+/* Row width of one entry of a frame-pair table (see slam_join_consensus). */
+#define SLAM_PAIR_STRIDE 8
 
 /* Largest train-set size of one matching (the packed (distance,index) key keeps
  * 22 bits for the index).  cv2's BFMatcher itself stops at 2^18 per image. */
 #define SLAM_MAX_TRAIN_ROWS (1 << 22)
-
-/* Upper bound on hypotheses per wavefront batch etc. are internal; limits that
- * a caller can hit are reported through slam_last_error(). */
 
 int slam_version(void);
 const char *slam_last_error(void);
@@ -138,10 +137,16 @@ int slam_triangulate_matched(const double *P_host, const double *Q_host,
  * Replaces: get_matches_that_appear_in_all_4_images (utils/utils.py:338-386)
  * and find_4_images_matches (models/LoopClosure.py:71-109).
  *
- * pair [n_pairs, 6] int32 dev: (prev_row0, prev_count, cur_row0, cur_count,
- * t_row0, unused) -- prev_row0/cur_row0 are the first rows of the earlier/later
- * frame in the per-left-keypoint tables (stereo_map, valid3d, X/Y/Z, xL..),
- * t_row0 the first row of this pair in the temporal match outputs.
+ * pair [n_pairs, 8] int32 dev, one row per frame pair (earlier frame "prev", later
+ * frame "cur"):
+ *   [0] prevL_row0  first row of prev's left keypoints in the per-left-keypoint
+ *                   tables (stereo_map, valid3d, X/Y/Z, xL, yL)
+ *   [1] prevL_count number of left keypoints of prev
+ *   [2] curL_row0, [3] curL_count   likewise for cur
+ *   [4] t_row0      first row of this pair in the temporal match outputs
+ *   [5] curR_row0   first row of cur's right keypoints in xR, yR
+ *   [6] prevR_row0  first row of prev's right keypoints in xR, yR
+ *   [7] unused
  * For each kept temporal match q -> t (ascending q) with stereo_map[prev q] >= 0,
  * stereo_map[cur t] >= 0 and valid3d[prev q]: emit one consensus row.
  *
@@ -152,8 +157,6 @@ int slam_triangulate_matched(const double *P_host, const double *Q_host,
  *   cuL,cvL f32  : pixel of cur_left in the later left image
  *   cuR,cvR f32  : pixel of cur_right in the later right image
  *   count [n_pairs] int32
- * xR/yR are indexed by right-keypoint rows: r_row0 [n_frames-like] is folded
- * into pair via cur_r_row0 = pair[...][5].
  */
 int slam_join_consensus(const int32_t *pair_dev, int n_pairs, int max_nq,
                         const int32_t *t_idx_dev, const uint8_t *t_keep_dev,
@@ -181,6 +184,11 @@ int slam_join_consensus(const int32_t *pair_dev, int n_pairs, int max_nq,
  * A point supports iff both reprojection distances are < thresh (strict), all
  * in fp64 with one rounding per operation in the reference's order; no
  * cheirality test.
+ * work_dev (nullable): caller-owned scratch of 6 * n_sets * cap doubles.  When it
+ * is given, masks_dev is NULL and K is a pinhole matrix [fx 0 cx; 0 fy cy; 0 0 1],
+ * evaluations are first run through a division-free filter and only the ones
+ * within a guard band of the threshold are evaluated in the reference's order;
+ * the counts are identical either way, the call is several times faster.
  */
 int slam_score_hypotheses(const double *Rt_dev, int n_sets, int H,
                           const double *K_host, const double *t_right_host,
@@ -189,7 +197,42 @@ int slam_score_hypotheses(const double *Rt_dev, int n_sets, int H,
                           const float *vL_dev, const float *uR_dev,
                           const float *vR_dev, int cap, const int32_t *n_dev,
                           int n_host, double thresh, int32_t *counts_dev,
-                          uint64_t *masks_dev, int mask_words, void *stream);
+                          uint64_t *masks_dev, int mask_words, double *work_dev,
+                          void *stream);
+
+/*
+ * Winner of a scored hypothesis set: the FIRST hypothesis with the largest
+ * supporter count, as ransac_for_pnp's strict '>' update keeps it
+ * (utils/utils.py:438-442) when every hypothesis is consumed.
+ * counts [n_sets, H] int32 dev; Rt [n_sets, H, 12] f64 dev (nullable with best_Rt).
+ * best, best_count [n_sets] int32; best_Rt [n_sets, 12] f64 (nullable).
+ */
+int slam_select_best(const int32_t *counts_dev, const double *Rt_dev, int n_sets,
+                     int H, int32_t *best_dev, int32_t *best_count_dev,
+                     double *best_Rt_dev, void *stream);
+
+/*
+ * Inlier tables of a batch of frame pairs: the consensus rows whose supporter
+ * bit is set, in order, each with the feature locations the track store keeps.
+ * Replaces: the Rt_inliers list comprehension (utils/utils.py:277-278) and the
+ * location lookups of TrackDatabase.update_tracks_from_frame
+ * (models/TrackDatabase.py:38-46).
+ *
+ * pair as for slam_join_consensus; rows/count/cap are its outputs; masks
+ * [n_pairs, mask_words] u64 is the supporter mask of ONE pose per pair
+ * (slam_score_hypotheses with H = 1).  out_off [n_pairs] int32 (nullable):
+ * first output slot of each pair (e.g. an exclusive prefix sum of the supporter
+ * counts, for dense tables); NULL means pair * cap.
+ * inl_rows [slots,4] int32 (prev_left, prev_right, cur_left, cur_right);
+ * inl_loc [slots,6] f32 (xl, xr, yl of prev; xl, xr, yl of cur); n_inl [n_pairs].
+ */
+int slam_build_inlier_tables(const int32_t *pair_dev, int n_pairs,
+                             const int32_t *rows_dev, const int32_t *count_dev,
+                             int cap, const uint64_t *masks_dev, int mask_words,
+                             const float *xL_dev, const float *yL_dev,
+                             const float *xR_dev, const int32_t *out_off_dev,
+                             int32_t *inl_rows_dev, float *inl_loc_dev,
+                             int32_t *n_inl_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,8 @@ EXPORTS = (
     "slam_triangulate_matched",
     "slam_join_consensus",
     "slam_score_hypotheses",
+    "slam_select_best",
+    "slam_build_inlier_tables",
 )
 
 
@@ -61,7 +63,11 @@ def load():
     lib.slam_join_consensus.restype = ci
     lib.slam_join_consensus.argtypes = [vp, ci, ci] + [vp] * 11 + [ci] + [vp] * 9 + [vp]
     lib.slam_score_hypotheses.restype = ci
-    lib.slam_score_hypotheses.argtypes = [vp, ci, ci, vp, vp] + [vp] * 7 + [ci, vp, ci, cd, vp, vp, ci, vp]
+    lib.slam_score_hypotheses.argtypes = [vp, ci, ci, vp, vp] + [vp] * 7 + [ci, vp, ci, cd, vp, vp, ci, vp, vp]
+    lib.slam_select_best.restype = ci
+    lib.slam_select_best.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
+    lib.slam_build_inlier_tables.restype = ci
+    lib.slam_build_inlier_tables.argtypes = [vp, ci, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp]
     _lib = lib
     return lib
 

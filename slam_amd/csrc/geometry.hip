@@ -1,4 +1,4 @@
-// DLT triangulation, four-image consensus join and PnP hypothesis scoring (gfx950).
+// DLT triangulation and four-image consensus join (gfx950).
 //
 // All fp64 arithmetic here is compiled with -ffp-contract=off and written in the
 // reference's operation order, one IEEE rounding per operation, so supporter
@@ -11,12 +11,6 @@ namespace {
 
 struct Mat34 {
     double m[12];
-};
-struct Mat33 {
-    double m[9];
-};
-struct Vec3 {
-    double v[3];
 };
 
 // ---------------------------------------------------------------------------
@@ -177,7 +171,7 @@ struct JoinArgs {
 __global__ void __launch_bounds__(256) join_kernel(const JoinArgs a)
 {
     __shared__ int wave_tot[4];
-    const int32_t *pr = a.pair + 6 * blockIdx.x;
+    const int32_t *pr = a.pair + SLAM_PAIR_STRIDE * blockIdx.x;
     const int p0 = pr[0], pn = pr[1], c0 = pr[2], cn = pr[3], t0 = pr[4], r0 = pr[5];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int base = 0;
@@ -219,114 +213,6 @@ __global__ void __launch_bounds__(256) join_kernel(const JoinArgs a)
     }
     if (tid == 0)
         a.count[blockIdx.x] = base;
-}
-
-// ---------------------------------------------------------------------------
-// Hypothesis scoring (utils/utils.py:389-410): exact fp64 in the written order.
-__device__ __forceinline__ bool supports(const double *__restrict__ rt, const Mat33 &K, const Vec3 &tr, double X,
-                                         double Y, double Z, double uL, double vL, double uR, double vR,
-                                         double thresh)
-{
-    const double L0 = ((rt[0] * X + rt[1] * Y) + rt[2] * Z) + rt[3];
-    const double L1 = ((rt[4] * X + rt[5] * Y) + rt[6] * Z) + rt[7];
-    const double L2 = ((rt[8] * X + rt[9] * Y) + rt[10] * Z) + rt[11];
-    const double R0 = L0 + tr.v[0], R1 = L1 + tr.v[1], R2 = L2 + tr.v[2];
-    const double hl0 = (K.m[0] * L0 + K.m[1] * L1) + K.m[2] * L2;
-    const double hl1 = (K.m[3] * L0 + K.m[4] * L1) + K.m[5] * L2;
-    const double hl2 = (K.m[6] * L0 + K.m[7] * L1) + K.m[8] * L2;
-    const double hr0 = (K.m[0] * R0 + K.m[1] * R1) + K.m[2] * R2;
-    const double hr1 = (K.m[3] * R0 + K.m[4] * R1) + K.m[5] * R2;
-    const double hr2 = (K.m[6] * R0 + K.m[7] * R1) + K.m[8] * R2;
-    const double plx = hl0 / hl2, ply = hl1 / hl2;
-    const double prx = hr0 / hr2, pry = hr1 / hr2;
-    const double dlx = uL - plx, dly = vL - ply;
-    const double drx = uR - prx, dry = vR - pry;
-    const double dl = sqrt(dlx * dlx + dly * dly);
-    const double dr = sqrt(drx * drx + dry * dry);
-    return (dl < thresh) && (dr < thresh);
-}
-
-struct ScoreArgs {
-    const double *Rt;
-    int H;
-    Mat33 K;
-    Vec3 tr;
-    const double *X, *Y, *Z;
-    const float *uL, *vL, *uR, *vR;
-    int cap;
-    const int32_t *n_dev;
-    int n_host;
-    double thresh;
-    int32_t *counts;
-    unsigned long long *masks;
-    int mask_words;
-    int blocks_per_set;
-};
-
-constexpr int SCORE_HPW = 2;  // hypotheses per wavefront (share the point loads)
-
-__global__ void __launch_bounds__(256) score_kernel(const ScoreArgs a)
-{
-    const int set = blockIdx.x / a.blocks_per_set;
-    const int blk = blockIdx.x - set * a.blocks_per_set;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int h0 = (blk * 4 + wave) * SCORE_HPW;
-    if (h0 >= a.H)
-        return;
-    int n = a.n_dev ? a.n_dev[set] : a.n_host;
-    n = min(max(n, 0), a.cap);
-    const size_t pbase = (size_t)set * a.cap;
-    double rt[SCORE_HPW][12];
-    bool live[SCORE_HPW];
-#pragma unroll
-    for (int e = 0; e < SCORE_HPW; ++e) {
-        live[e] = (h0 + e) < a.H;
-        const double *src = a.Rt + ((size_t)set * a.H + (live[e] ? h0 + e : h0)) * 12;
-#pragma unroll
-        for (int c = 0; c < 12; ++c)
-            rt[e][c] = src[c];
-    }
-    int cnt[SCORE_HPW];
-#pragma unroll
-    for (int e = 0; e < SCORE_HPW; ++e)
-        cnt[e] = 0;
-    for (int base = 0; base < n; base += 64) {
-        const int i = base + lane;
-        const bool in = i < n;
-        const size_t o = pbase + (in ? i : 0);
-        const double X = a.X[o], Y = a.Y[o], Z = a.Z[o];
-        const double uL = (double)a.uL[o], vL = (double)a.vL[o], uR = (double)a.uR[o], vR = (double)a.vR[o];
-#pragma unroll
-        for (int e = 0; e < SCORE_HPW; ++e) {
-            const bool s = in && supports(rt[e], a.K, a.tr, X, Y, Z, uL, vL, uR, vR, a.thresh);
-            const unsigned long long m = __ballot(s);
-            cnt[e] += __popcll(m);
-            if (a.masks && live[e] && lane == 0)
-                a.masks[((size_t)set * a.H + h0 + e) * a.mask_words + (base >> 6)] = m;
-        }
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int e = 0; e < SCORE_HPW; ++e)
-            if (live[e])
-                a.counts[(size_t)set * a.H + h0 + e] = cnt[e];
-    }
-}
-
-// Clears mask words that the scoring loop does not reach (words past ceil(n/64)).
-__global__ void __launch_bounds__(256) clear_mask_tail_kernel(unsigned long long *masks, int n_sets, int H,
-                                                              int mask_words, const int32_t *n_dev, int n_host, int cap)
-{
-    const size_t total = (size_t)n_sets * H * mask_words;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const int w = (int)(e % mask_words);
-        const int set = (int)(e / ((size_t)H * mask_words));
-        int n = n_dev ? n_dev[set] : n_host;
-        n = min(max(n, 0), cap);
-        if (w >= (n + 63) / 64)
-            masks[e] = 0ull;
-    }
 }
 
 Mat34 load34(const double *p)
@@ -437,59 +323,4 @@ extern "C" int slam_join_consensus(const int32_t *pair, int n_pairs, int max_nq,
     a.count = count;
     hipLaunchKernelGGL(join_kernel, dim3(n_pairs), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("slam_join_consensus");
-}
-
-extern "C" int slam_score_hypotheses(const double *Rt, int n_sets, int H, const double *K, const double *t_right,
-                                     const double *X, const double *Y, const double *Z, const float *uL,
-                                     const float *vL, const float *uR, const float *vR, int cap, const int32_t *n_dev,
-                                     int n_host, double thresh, int32_t *counts, uint64_t *masks, int mask_words,
-                                     void *stream)
-{
-    if (n_sets < 0 || H < 0 || cap < 0)
-        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: negative size");
-    if (!K || !t_right)
-        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: null intrinsics");
-    if (n_sets == 0 || H == 0)
-        return SLAM_OK;
-    if (!Rt || !counts)
-        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: null buffer");
-    if (cap > 0 && (!X || !Y || !Z || !uL || !vL || !uR || !vR))
-        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: null point buffer");
-    if (masks && mask_words < (cap + 63) / 64)
-        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: mask_words %d < ceil(cap/64) = %d", mask_words,
-                    (cap + 63) / 64);
-    ScoreArgs a;
-    a.Rt = Rt;
-    a.H = H;
-    for (int i = 0; i < 9; ++i)
-        a.K.m[i] = K[i];
-    for (int i = 0; i < 3; ++i)
-        a.tr.v[i] = t_right[i];
-    a.X = X;
-    a.Y = Y;
-    a.Z = Z;
-    a.uL = uL;
-    a.vL = vL;
-    a.uR = uR;
-    a.vR = vR;
-    a.cap = cap;
-    a.n_dev = n_dev;
-    a.n_host = n_host;
-    a.thresh = thresh;
-    a.counts = counts;
-    a.masks = reinterpret_cast<unsigned long long *>(masks);
-    a.mask_words = mask_words;
-    a.blocks_per_set = (H + 4 * SCORE_HPW - 1) / (4 * SCORE_HPW);
-    const long long blocks = (long long)n_sets * a.blocks_per_set;
-    if (blocks > 0x7FFFFFFFLL)
-        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: grid too large");
-    hipStream_t s = (hipStream_t)stream;
-    if (masks && mask_words > 0) {
-        const size_t total = (size_t)n_sets * H * mask_words;
-        const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-        hipLaunchKernelGGL(clear_mask_tail_kernel, dim3(grid), dim3(256), 0, s, a.masks, n_sets, H, mask_words, n_dev,
-                           n_host, cap);
-    }
-    hipLaunchKernelGGL(score_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
-    return check_launch("slam_score_hypotheses");
 }

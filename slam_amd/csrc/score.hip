@@ -1,0 +1,343 @@
+// PnP-RANSAC hypothesis scoring (find_supporters, utils/utils.py:389-410) on gfx950.
+//
+// The verdict for one (hypothesis, point) evaluation is DEFINED by `supports()` below:
+// fp64, the reference's operation order, one IEEE rounding per operation (this file is
+// compiled with -ffp-contract=off), strict '<' on both pixel distances.
+//
+// Two kernels produce that verdict:
+//
+//  score_kernel       lane = point, one wavefront per 2 hypotheses; evaluates
+//                     supports() for every pair; ballot/popcount gives the count and
+//                     the supporter bit mask.  Used when masks are wanted, for
+//                     general K, or without a workspace.
+//
+//  score_fast_kernel  lane = hypothesis (pose in VGPRs), the point loop is
+//                     wave-uniform so point data arrives through scalar loads and
+//                     costs no VALU.  Each evaluation first runs a division- and
+//                     sqrt-free *filter* in fused fp64 arithmetic:
+//                         dx = (u-cx)*hz - fx*L0,  dy = (v-cy)*hz - fy*L1,
+//                         s = dx^2 + dy^2   versus   T = (thresh*hz)^2
+//                     (the reference's test multiplied through by hz^2).  With a
+//                     per-point relative guard band kappa the filter answers "in" if
+//                     s - T < -kappa*(s+T), "out" if s - T > kappa*(s+T) for either
+//                     camera, and otherwise -- or when hz is tiny against the
+//                     magnitude of the terms it was summed from, or anything is
+//                     NaN/Inf -- the lane falls through to supports().  The band is
+//                     ~2^-26 * (|K| + |uv| + thresh)/thresh, at least 16x the worst
+//                     rounding gap between the two evaluation orders, so the filter
+//                     never contradicts supports(): counts are bit-identical, only
+//                     ~4x cheaper (about 40 fp64 VALU ops per evaluation instead of
+//                     ~60 plus four divisions and two square roots).
+#include "common.h"
+
+namespace slam {
+namespace {
+
+struct Mat33 {
+    double m[9];
+};
+struct Vec3 {
+    double v[3];
+};
+
+__device__ __forceinline__ bool supports(const double *__restrict__ rt, const Mat33 &K, const Vec3 &tr, double X,
+                                         double Y, double Z, double uL, double vL, double uR, double vR,
+                                         double thresh)
+{
+    const double L0 = ((rt[0] * X + rt[1] * Y) + rt[2] * Z) + rt[3];
+    const double L1 = ((rt[4] * X + rt[5] * Y) + rt[6] * Z) + rt[7];
+    const double L2 = ((rt[8] * X + rt[9] * Y) + rt[10] * Z) + rt[11];
+    const double R0 = L0 + tr.v[0], R1 = L1 + tr.v[1], R2 = L2 + tr.v[2];
+    const double hl0 = (K.m[0] * L0 + K.m[1] * L1) + K.m[2] * L2;
+    const double hl1 = (K.m[3] * L0 + K.m[4] * L1) + K.m[5] * L2;
+    const double hl2 = (K.m[6] * L0 + K.m[7] * L1) + K.m[8] * L2;
+    const double hr0 = (K.m[0] * R0 + K.m[1] * R1) + K.m[2] * R2;
+    const double hr1 = (K.m[3] * R0 + K.m[4] * R1) + K.m[5] * R2;
+    const double hr2 = (K.m[6] * R0 + K.m[7] * R1) + K.m[8] * R2;
+    const double plx = hl0 / hl2, ply = hl1 / hl2;
+    const double prx = hr0 / hr2, pry = hr1 / hr2;
+    const double dlx = uL - plx, dly = vL - ply;
+    const double drx = uR - prx, dry = vR - pry;
+    const double dl = sqrt(dlx * dlx + dly * dly);
+    const double dr = sqrt(drx * drx + dry * dry);
+    return (dl < thresh) && (dr < thresh);
+}
+
+struct ScoreArgs {
+    const double *Rt;
+    int H;
+    Mat33 K;
+    Vec3 tr;
+    const double *X, *Y, *Z;
+    const float *uL, *vL, *uR, *vR;
+    int cap;
+    const int32_t *n_dev;
+    int n_host;
+    double thresh;
+    int32_t *counts;
+    unsigned long long *masks;
+    int mask_words;
+    int blocks_per_set;
+    double *work;      // [6][n_sets*cap]: a, b, ar, br, A, kappa (fast path only)
+    size_t wstride;    // n_sets*cap
+    double trmax;      // max |t_right[i]|
+};
+
+constexpr int SCORE_HPW = 2;  // hypotheses per wavefront (share the point loads)
+
+__global__ void __launch_bounds__(256) score_kernel(const ScoreArgs a)
+{
+    const int set = blockIdx.x / a.blocks_per_set;
+    const int blk = blockIdx.x - set * a.blocks_per_set;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h0 = (blk * 4 + wave) * SCORE_HPW;
+    if (h0 >= a.H)
+        return;
+    int n = a.n_dev ? a.n_dev[set] : a.n_host;
+    n = min(max(n, 0), a.cap);
+    const size_t pbase = (size_t)set * a.cap;
+    double rt[SCORE_HPW][12];
+    bool live[SCORE_HPW];
+#pragma unroll
+    for (int e = 0; e < SCORE_HPW; ++e) {
+        live[e] = (h0 + e) < a.H;
+        const double *src = a.Rt + ((size_t)set * a.H + (live[e] ? h0 + e : h0)) * 12;
+#pragma unroll
+        for (int c = 0; c < 12; ++c)
+            rt[e][c] = src[c];
+    }
+    int cnt[SCORE_HPW];
+#pragma unroll
+    for (int e = 0; e < SCORE_HPW; ++e)
+        cnt[e] = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool in = i < n;
+        const size_t o = pbase + (in ? i : 0);
+        const double X = a.X[o], Y = a.Y[o], Z = a.Z[o];
+        const double uL = (double)a.uL[o], vL = (double)a.vL[o], uR = (double)a.uR[o], vR = (double)a.vR[o];
+#pragma unroll
+        for (int e = 0; e < SCORE_HPW; ++e) {
+            const bool s = in && supports(rt[e], a.K, a.tr, X, Y, Z, uL, vL, uR, vR, a.thresh);
+            const unsigned long long m = __ballot(s);
+            cnt[e] += __popcll(m);
+            if (a.masks && live[e] && lane == 0)
+                a.masks[((size_t)set * a.H + h0 + e) * a.mask_words + (base >> 6)] = m;
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int e = 0; e < SCORE_HPW; ++e)
+            if (live[e])
+                a.counts[(size_t)set * a.H + h0 + e] = cnt[e];
+    }
+}
+
+// Clears mask words that the scoring loop does not reach (words past ceil(n/64)).
+__global__ void __launch_bounds__(256) clear_mask_tail_kernel(unsigned long long *masks, int n_sets, int H,
+                                                              int mask_words, const int32_t *n_dev, int n_host, int cap)
+{
+    const size_t total = (size_t)n_sets * H * mask_words;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int w = (int)(e % mask_words);
+        const int set = (int)(e / ((size_t)H * mask_words));
+        int n = n_dev ? n_dev[set] : n_host;
+        n = min(max(n, 0), cap);
+        if (w >= (n + 63) / 64)
+            masks[e] = 0ull;
+    }
+}
+
+// ---- fast path ---------------------------------------------------------------
+// Per-point quantities the filter needs, computed once per call instead of once per
+// hypothesis: pixel offsets from the principal point, the magnitude A = |X|+|Y|+|Z|
+// that bounds every partial sum of Rt @ [X,1], and the guard band kappa.
+__global__ void __launch_bounds__(256) score_prep_kernel(const ScoreArgs a, int n_sets)
+{
+    const size_t total = (size_t)n_sets * a.cap;
+    const double fx = a.K.m[0], fy = a.K.m[4], cx = a.K.m[2], cy = a.K.m[5];
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const double uL = (double)a.uL[o], vL = (double)a.vL[o], uR = (double)a.uR[o], vR = (double)a.vR[o];
+        a.work[0 * a.wstride + o] = uL - cx;
+        a.work[1 * a.wstride + o] = vL - cy;
+        a.work[2 * a.wstride + o] = uR - cx;
+        a.work[3 * a.wstride + o] = vR - cy;
+        a.work[4 * a.wstride + o] = (fabs(a.X[o]) + fabs(a.Y[o])) + fabs(a.Z[o]);
+        const double mag = fabs(fx) + fabs(fy) + fabs(cx) + fabs(cy) + fabs(uL) + fabs(vL) + fabs(uR) + fabs(vR) +
+                           fabs(a.thresh);
+        // 2^-25 * mag / thresh + 2^-26; thresh <= 0 or NaN gives inf/NaN -> every lane takes the exact path
+        double kappa = 2.98023223876953125e-8 * (mag / a.thresh) + 1.490116119384765625e-8;
+        if (!(a.thresh > 0.0) || !(kappa < 0.25))
+            kappa = __builtin_inf();
+        a.work[5 * a.wstride + o] = kappa;
+    }
+}
+
+__global__ void __launch_bounds__(256) score_fast_kernel(const ScoreArgs a)
+{
+    const int set = blockIdx.x / a.blocks_per_set;
+    const int blk = blockIdx.x - set * a.blocks_per_set;
+    const int h = blk * 256 + threadIdx.x;
+    if ((blk * 256 + (int)(threadIdx.x & ~63u)) >= a.H)
+        return;  // whole wavefront past the last hypothesis
+    const bool live = h < a.H;
+    const double *src = a.Rt + ((size_t)set * a.H + (live ? h : a.H - 1)) * 12;
+    double rt[12];
+#pragma unroll
+    for (int c = 0; c < 12; c += 2) {
+        const double2 v = *reinterpret_cast<const double2 *>(src + c);
+        rt[c] = v.x;
+        rt[c + 1] = v.y;
+    }
+    double Bh = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            Bh = fmax(Bh, fabs(rt[4 * r + c]));
+    const double Tm = fmax(fmax(fabs(rt[3]), fabs(rt[7])), fabs(rt[11])) + a.trmax;
+    // NaN anywhere in the pose must reach the exact path: fmax drops NaNs, so test it here
+    bool pose_ok = true;
+#pragma unroll
+    for (int c = 0; c < 12; ++c)
+        pose_ok = pose_ok && (fabs(rt[c]) < __builtin_inf());
+
+    int n = a.n_dev ? a.n_dev[set] : a.n_host;
+    n = min(max(n, 0), a.cap);
+    n = __builtin_amdgcn_readfirstlane(n);
+    const size_t pbase = (size_t)set * a.cap;
+    const double fx = a.K.m[0], fy = a.K.m[4];
+    const double t0 = a.tr.v[0], t1 = a.tr.v[1], t2 = a.tr.v[2];
+    const double thr = a.thresh;
+    const double *__restrict__ gX = a.X + pbase;
+    const double *__restrict__ gY = a.Y + pbase;
+    const double *__restrict__ gZ = a.Z + pbase;
+    const double *__restrict__ wa = a.work + 0 * a.wstride + pbase;
+    const double *__restrict__ wb = a.work + 1 * a.wstride + pbase;
+    const double *__restrict__ war = a.work + 2 * a.wstride + pbase;
+    const double *__restrict__ wbr = a.work + 3 * a.wstride + pbase;
+    const double *__restrict__ wA = a.work + 4 * a.wstride + pbase;
+    const double *__restrict__ wk = a.work + 5 * a.wstride + pbase;
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+        const double X = gX[i], Y = gY[i], Z = gZ[i];
+        const double pa = wa[i], pb = wb[i], par = war[i], pbr = wbr[i], A = wA[i], kap = wk[i];
+        // filter: fused arithmetic, no division, no square root
+        const double L0 = __builtin_fma(rt[0], X, __builtin_fma(rt[1], Y, __builtin_fma(rt[2], Z, rt[3])));
+        const double L1 = __builtin_fma(rt[4], X, __builtin_fma(rt[5], Y, __builtin_fma(rt[6], Z, rt[7])));
+        const double L2 = __builtin_fma(rt[8], X, __builtin_fma(rt[9], Y, __builtin_fma(rt[10], Z, rt[11])));
+        const double R0 = L0 + t0, R1 = L1 + t1, R2 = L2 + t2;
+        const double dxl = __builtin_fma(pa, L2, -(fx * L0));
+        const double dyl = __builtin_fma(pb, L2, -(fy * L1));
+        const double dxr = __builtin_fma(par, R2, -(fx * R0));
+        const double dyr = __builtin_fma(pbr, R2, -(fy * R1));
+        const double sl = __builtin_fma(dxl, dxl, dyl * dyl);
+        const double sr = __builtin_fma(dxr, dxr, dyr * dyr);
+        const double tl = thr * L2, tr_ = thr * R2;
+        const double Tl = tl * tl, Tr = tr_ * tr_;
+        const double ml = kap * (sl + Tl), mr = kap * (sr + Tr);
+        const double dl = sl - Tl, dr = sr - Tr;
+        const double S = __builtin_fma(Bh, A, Tm) * 9.5367431640625e-07;  // 2^-20 * magnitude of the summed terms
+        const bool tiny = !(fabs(L2) > S) || !(fabs(R2) > S);
+        const bool sure_in = (dl < -ml) && (dr < -mr);
+        const bool sure_out = (dl > ml) || (dr > mr);
+        bool s = sure_in;
+        if (tiny || !pose_ok || !(sure_in || sure_out)) {
+            const size_t o = pbase + i;
+            s = supports(rt, a.K, a.tr, X, Y, Z, (double)a.uL[o], (double)a.vL[o], (double)a.uR[o], (double)a.vR[o],
+                         thr);
+        }
+        cnt += s ? 1 : 0;
+    }
+    if (live)
+        a.counts[(size_t)set * a.H + h] = cnt;
+}
+
+}  // namespace
+}  // namespace slam
+
+using namespace slam;
+
+extern "C" int slam_score_hypotheses(const double *Rt, int n_sets, int H, const double *K, const double *t_right,
+                                     const double *X, const double *Y, const double *Z, const float *uL,
+                                     const float *vL, const float *uR, const float *vR, int cap, const int32_t *n_dev,
+                                     int n_host, double thresh, int32_t *counts, uint64_t *masks, int mask_words,
+                                     double *work, void *stream)
+{
+    if (n_sets < 0 || H < 0 || cap < 0)
+        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: negative size");
+    if (!K || !t_right)
+        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: null intrinsics");
+    if (n_sets == 0 || H == 0)
+        return SLAM_OK;
+    if (!Rt || !counts)
+        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: null buffer");
+    if (cap > 0 && (!X || !Y || !Z || !uL || !vL || !uR || !vR))
+        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: null point buffer");
+    if (masks && mask_words < (cap + 63) / 64)
+        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: mask_words %d < ceil(cap/64) = %d", mask_words,
+                    (cap + 63) / 64);
+    if (reinterpret_cast<uintptr_t>(Rt) & 15)
+        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: Rt must be 16-byte aligned");
+    ScoreArgs a;
+    a.Rt = Rt;
+    a.H = H;
+    for (int i = 0; i < 9; ++i)
+        a.K.m[i] = K[i];
+    a.trmax = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        a.tr.v[i] = t_right[i];
+        const double m = t_right[i] < 0 ? -t_right[i] : t_right[i];
+        a.trmax = m > a.trmax ? m : a.trmax;   // a NaN here stays out of trmax; supports() still sees it
+    }
+    a.X = X;
+    a.Y = Y;
+    a.Z = Z;
+    a.uL = uL;
+    a.vL = vL;
+    a.uR = uR;
+    a.vR = vR;
+    a.cap = cap;
+    a.n_dev = n_dev;
+    a.n_host = n_host;
+    a.thresh = thresh;
+    a.counts = counts;
+    a.masks = reinterpret_cast<unsigned long long *>(masks);
+    a.mask_words = mask_words;
+    a.work = work;
+    a.wstride = (size_t)n_sets * cap;
+    hipStream_t s = (hipStream_t)stream;
+
+    // The filter is written for the pinhole pattern K = [fx 0 cx; 0 fy cy; 0 0 1]
+    // (for which the skipped products are exact zeros) and finite camera constants.
+    bool pinhole = K[1] == 0.0 && K[3] == 0.0 && K[6] == 0.0 && K[7] == 0.0 && K[8] == 1.0;
+    for (int i = 0; i < 9; ++i)
+        pinhole = pinhole && (K[i] - K[i] == 0.0);
+    for (int i = 0; i < 3; ++i)
+        pinhole = pinhole && (t_right[i] - t_right[i] == 0.0);
+    if (work && !masks && pinhole && cap > 0) {
+        const size_t total = (size_t)n_sets * cap;
+        const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(score_prep_kernel, dim3(grid), dim3(256), 0, s, a, n_sets);
+        a.blocks_per_set = (H + 255) / 256;
+        const long long blocks = (long long)n_sets * a.blocks_per_set;
+        if (blocks > 0x7FFFFFFFLL)
+            return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: grid too large");
+        hipLaunchKernelGGL(score_fast_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        return check_launch("slam_score_hypotheses(fast)");
+    }
+
+    a.blocks_per_set = (H + 4 * SCORE_HPW - 1) / (4 * SCORE_HPW);
+    const long long blocks = (long long)n_sets * a.blocks_per_set;
+    if (blocks > 0x7FFFFFFFLL)
+        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: grid too large");
+    if (masks && mask_words > 0) {
+        const size_t total = (size_t)n_sets * H * mask_words;
+        const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(clear_mask_tail_kernel, dim3(grid), dim3(256), 0, s, a.masks, n_sets, H, mask_words, n_dev,
+                           n_host, cap);
+    }
+    hipLaunchKernelGGL(score_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return check_launch("slam_score_hypotheses");
+}

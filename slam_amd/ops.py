@@ -173,7 +173,8 @@ class Consensus:
 def join_consensus(pair, max_nq, t_idx, t_keep, stereo_map, valid3d, X, Y, Z, xL, yL, xR, yR, cap):
     """Four-image consensus join for a batch of frame pairs (slam_join_consensus).
 
-    pair: [n_pairs,6] int32 (prev_row0, prev_count, cur_row0, cur_count, t_row0, cur_right_row0).
+    pair: [n_pairs,8] int32 (prevL_row0, prevL_count, curL_row0, curL_count, t_row0, curR_row0,
+    prevR_row0, 0).
     """
     lib = _lib.load()
     n_pairs = pair.shape[0]
@@ -192,12 +193,14 @@ def join_consensus(pair, max_nq, t_idx, t_keep, stereo_map, valid3d, X, Y, Z, xL
 
 
 def score_hypotheses(Rt, K, t_right, X, Y, Z, uL, vL, uR, vR, thresh=2.0, cap=None, n_dev=None, n_host=None,
-                     want_masks=False):
+                     want_masks=False, work=None, fast=True):
     """Supporter counts of H pose hypotheses per point set (slam_score_hypotheses).
 
     Rt: [n_sets, H, 3, 4] (or [H,3,4] for one set) f64.  Points: flat SoA with set s
     at [s*cap, s*cap+n_s).  Returns counts [n_sets,H] i32 (and masks [n_sets,H,words] as
-    int64 bit patterns when want_masks).
+    int64 bit patterns when want_masks).  `fast` lets the library use its filtered path
+    (needs a scratch tensor `work` of 6*n_sets*cap doubles, allocated here if absent);
+    counts are identical with fast=False.
     """
     lib = _lib.load()
     if Rt.dim() == 3:
@@ -214,12 +217,15 @@ def score_hypotheses(Rt, K, t_right, X, Y, Z, uL, vL, uR, vR, thresh=2.0, cap=No
     words = (cap + 63) // 64
     masks = torch.zeros((n_sets, H, max(words, 1)), dtype=torch.int64, device=dev) if want_masks else None
     null = ctypes.c_void_p(0)
+    if fast and not want_masks and work is None:
+        work = torch.empty(6 * max(n_sets * cap, 1), dtype=torch.float64, device=dev)
     st = lib.slam_score_hypotheses(
         _dev(Rt, torch.float64, "Rt"), n_sets, H, pK, pt, _dev(X, torch.float64, "X"), _dev(Y, torch.float64, "Y"),
         _dev(Z, torch.float64, "Z"), _dev(uL, torch.float32, "uL"), _dev(vL, torch.float32, "vL"),
         _dev(uR, torch.float32, "uR"), _dev(vR, torch.float32, "vR"), int(cap),
         _dev(n_dev, torch.int32, "n_dev") if n_dev is not None else null, int(n_host), float(thresh),
         ctypes.c_void_p(counts.data_ptr()), ctypes.c_void_p(masks.data_ptr()) if masks is not None else null,
-        max(words, 1) if masks is not None else 0, _stream())
+        max(words, 1) if masks is not None else 0,
+        _dev(work, torch.float64, "work") if (fast and work is not None) else null, _stream())
     _lib.check(st, "slam_score_hypotheses")
     return (counts, masks) if want_masks else counts

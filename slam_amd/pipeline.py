@@ -1,0 +1,224 @@
+"""Device-resident, batched front-end over a contiguous range of stereo frames.
+
+This is the fast path: where the reference walks frame by frame through Python
+(track_camera_for_many_images, utils/utils.py:236-294), a frame range is laid out
+once as structure-of-arrays tables in HBM and each stage is ONE kernel launch over
+the whole range:
+
+  1. stereo matching L_f -> R_f (k = 1) + row filter      utils/utils.py:302-315
+  2. DLT triangulation of every kept stereo match          utils/utils.py:318-335
+  3. temporal matching L_f -> L_{f+1} (k = 2) + ratio test  models/Matcher.py:187-204
+  4. four-image consensus join per pair (f, f+1)           utils/utils.py:338-386
+  5. supporter counting of H pose hypotheses per pair      utils/utils.py:389-410
+  6. first-best winner, its supporter mask, inlier tables    utils/utils.py:438-442,455,277-278
+
+Nothing is copied back to the host between stages.  Buffers are allocated once per
+(frame range, H) by `FrontEnd.prepare` and reused by every `run`.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+
+class FrameTables:
+    """SoA keypoint / descriptor tables of F stereo frames in HBM.
+
+    descL/descR: [rows, 32|64] uint8, zero padded; xL,yL,xR,yR: [rows] float32;
+    offL/offR: host int64 [F+1] row offsets of each frame's left/right keypoints.
+    """
+
+    def __init__(self, descL, descR, xL, yL, xR, yR, offL, offR, desc_bytes):
+        self.descL, self.descR = descL, descR
+        self.xL, self.yL, self.xR, self.yR = xL, yL, xR, yR
+        self.offL = np.asarray(offL, dtype=np.int64)
+        self.offR = np.asarray(offR, dtype=np.int64)
+        self.desc_bytes = int(desc_bytes)
+        self.n_frames = len(self.offL) - 1
+        self.device = descL.device
+
+    @classmethod
+    def from_frames(cls, frames, device):
+        """frames: objects with kpL/kpR [N,2] float32 and descL/descR [N,D] uint8."""
+        D = frames[0].descL.shape[1]
+        stride = 32 if D <= 32 else 64
+        if D > 64:
+            raise ValueError("descriptors longer than 64 bytes are not supported")
+
+        def table(arrs):
+            raw = np.ascontiguousarray(np.concatenate(arrs, axis=0))
+            return ops.pack_descriptors(torch.from_numpy(raw).to(device), D, stride)
+
+        def col(side, c):
+            a = np.concatenate([getattr(f, side)[:, c] for f in frames]).astype(np.float32)
+            return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+        offL = np.concatenate([[0], np.cumsum([f.descL.shape[0] for f in frames])])
+        offR = np.concatenate([[0], np.cumsum([f.descR.shape[0] for f in frames])])
+        return cls(table([f.descL for f in frames]), table([f.descR for f in frames]), col("kpL", 0), col("kpL", 1),
+                   col("kpR", 0), col("kpR", 1), offL, offR, D)
+
+
+class Workspace:
+    """Every buffer one FrontEnd.run touches, allocated once."""
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+class FrontEnd:
+    def __init__(self, k, m1, m2, row_thresh=2.0, ratio_thresh=1.0, pix_thresh=2.0):
+        """k, m1, m2 as returned by read_cameras (utils/utils.py:75-86)."""
+        self.k = np.ascontiguousarray(k, dtype=np.float64)
+        self.P = np.ascontiguousarray(self.k @ np.asarray(m1, dtype=np.float64))   # utils/utils.py:325
+        self.Q = np.ascontiguousarray(self.k @ np.asarray(m2, dtype=np.float64))
+        self.t_right = np.ascontiguousarray(np.asarray(m2, dtype=np.float64)[:, 3])  # utils/utils.py:396
+        self.row_thresh, self.ratio_thresh, self.pix_thresh = float(row_thresh), float(ratio_thresh), float(pix_thresh)
+        self.lib = _lib.load()
+
+    def prepare(self, tb, n_hyp=0, want_masks=False):
+        """Allocate outputs and index tables for the frame range held by `tb`."""
+        dev = tb.device
+        F = tb.n_frames
+        nL = np.diff(tb.offL)
+        nR = np.diff(tb.offR)
+        ws = Workspace()
+        ws.tb, ws.F, ws.P, ws.H = tb, F, max(F - 1, 0), int(n_hyp)
+        ws.max_nL, ws.max_nR = int(nL.max()) if F else 0, int(nR.max()) if F else 0
+        rows = int(tb.offL[-1])
+        ws.rows = rows
+        ws.seg_s = ops.make_segments(tb.offL[:-1], nL, tb.offR[:-1], nR, tb.offL[:-1], dev)
+        ws.seg_t = ops.make_segments(tb.offL[:-2], nL[:-1], tb.offL[1:-1], nL[1:], tb.offL[:-2], dev)
+        pair = np.stack([tb.offL[:-2], nL[:-1], tb.offL[1:-1], nL[1:], tb.offL[:-2], tb.offR[1:-1], tb.offR[:-2],
+                         np.zeros(max(F - 1, 0), dtype=np.int64)], axis=1)
+        ws.pair = torch.from_numpy(pair.astype(np.int32).reshape(-1, 8)).to(dev)
+        i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
+        u8 = lambda *s: torch.empty(s, dtype=torch.uint8, device=dev)
+        f64 = lambda *s: torch.empty(s, dtype=torch.float64, device=dev)
+        r = max(rows, 1)
+        ws.s_idx, ws.s_dist, ws.s_keep = i32(r, 2), i32(r, 2), u8(r)
+        ws.X, ws.Y, ws.Z, ws.valid, ws.smap = f64(r), f64(r), f64(r), u8(r), i32(r)
+        ws.t_idx, ws.t_dist, ws.t_keep = i32(r, 2), i32(r, 2), u8(r)
+        ws.cap = ws.max_nL
+        ws.cons = ops.Consensus(ws.P, ws.cap, dev)
+        ws.counts = torch.zeros((max(ws.P, 1), max(ws.H, 1)), dtype=torch.int32, device=dev)
+        ws.mask_words = (ws.cap + 63) // 64
+        ws.masks = (torch.zeros((max(ws.P, 1), max(ws.H, 1), max(ws.mask_words, 1)), dtype=torch.int64, device=dev)
+                    if want_masks else None)
+        ws.score_work = f64(6 * max(ws.P * ws.cap, 1))
+        # winner selection + inlier tables
+        np_ = max(ws.P, 1)
+        ws.best, ws.best_count = i32(np_), i32(np_)
+        ws.best_Rt = f64(np_, 12)
+        ws.final_count = torch.zeros((np_, 1), dtype=torch.int32, device=dev)
+        ws.final_mask = torch.zeros((np_, 1, max(ws.mask_words, 1)), dtype=torch.int64, device=dev)
+        ws.inl_off = i32(np_)
+        ws.inl_rows = i32(max(ws.P * ws.cap, 1), 4)
+        ws.inl_loc = torch.empty((max(ws.P * ws.cap, 1), 6), dtype=torch.float32, device=dev)
+        ws.n_inl = i32(np_)
+        # host constants must outlive the calls
+        ws.hP = self.P.ctypes.data_as(ctypes.c_void_p)
+        ws.hQ = self.Q.ctypes.data_as(ctypes.c_void_p)
+        ws.hK = self.k.ctypes.data_as(ctypes.c_void_p)
+        ws.hT = self.t_right.ctypes.data_as(ctypes.c_void_p)
+        return ws
+
+    # -- the five launches ---------------------------------------------------
+    def stereo_match(self, ws, stream):
+        tb = ws.tb
+        st = self.lib.slam_hamming_match(_p(tb.descL), _p(tb.descR), _p(ws.seg_s), ws.F, ws.max_nL, ws.max_nR,
+                                         tb.desc_bytes, tb.descL.shape[1], 1, 2, self.row_thresh, _p(tb.yL),
+                                         _p(tb.yR), _p(ws.s_idx), _p(ws.s_dist), _p(ws.s_keep), stream)
+        _lib.check(st, "slam_hamming_match(stereo)")
+
+    def triangulate(self, ws, stream):
+        tb = ws.tb
+        st = self.lib.slam_triangulate_matched(ws.hP, ws.hQ, _p(tb.xL), _p(tb.yL), _p(tb.xR), _p(tb.yR), _p(ws.seg_s),
+                                               ws.F, ws.max_nL, _p(ws.s_idx), _p(ws.s_keep), _p(ws.X), _p(ws.Y),
+                                               _p(ws.Z), _p(ws.valid), _p(ws.smap), stream)
+        _lib.check(st, "slam_triangulate_matched")
+
+    def temporal_match(self, ws, stream):
+        tb = ws.tb
+        st = self.lib.slam_hamming_match(_p(tb.descL), _p(tb.descL), _p(ws.seg_t), ws.P, ws.max_nL, ws.max_nL,
+                                         tb.desc_bytes, tb.descL.shape[1], 2, 1, self.ratio_thresh, None, None,
+                                         _p(ws.t_idx), _p(ws.t_dist), _p(ws.t_keep), stream)
+        _lib.check(st, "slam_hamming_match(temporal)")
+
+    def join(self, ws, stream):
+        tb, c = ws.tb, ws.cons
+        st = self.lib.slam_join_consensus(_p(ws.pair), ws.P, ws.max_nL, _p(ws.t_idx), _p(ws.t_keep), _p(ws.smap),
+                                          _p(ws.valid), _p(ws.X), _p(ws.Y), _p(ws.Z), _p(tb.xL), _p(tb.yL), _p(tb.xR),
+                                          _p(tb.yR), ws.cap, _p(c.rows), _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL),
+                                          _p(c.vL), _p(c.uR), _p(c.vR), _p(c.count), stream)
+        _lib.check(st, "slam_join_consensus")
+
+    def score(self, ws, Rt, stream):
+        """Rt: [P, H, 3, 4] (or [P,H,12]) float64 on the device."""
+        c = ws.cons
+        st = self.lib.slam_score_hypotheses(_p(Rt), ws.P, ws.H, ws.hK, ws.hT, _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL),
+                                            _p(c.vL), _p(c.uR), _p(c.vR), ws.cap, _p(c.count), 0, self.pix_thresh,
+                                            _p(ws.counts), _p(ws.masks), ws.mask_words if ws.masks is not None else 0,
+                                            _p(ws.score_work), stream)
+        _lib.check(st, "slam_score_hypotheses")
+
+    def select(self, ws, Rt, stream, dense=True):
+        """Winner per pair (first best), its supporter mask (one more scoring call with
+        H = 1, as the reference's final find_supporters, utils/utils.py:455) and the
+        order-preserving inlier tables; dense=True packs the pairs back to back."""
+        c = ws.cons
+        st = self.lib.slam_select_best(_p(ws.counts), _p(Rt), ws.P, ws.H, _p(ws.best), _p(ws.best_count),
+                                       _p(ws.best_Rt), stream)
+        _lib.check(st, "slam_select_best")
+        st = self.lib.slam_score_hypotheses(_p(ws.best_Rt), ws.P, 1, ws.hK, ws.hT, _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL),
+                                            _p(c.vL), _p(c.uR), _p(c.vR), ws.cap, _p(c.count), 0, self.pix_thresh,
+                                            _p(ws.final_count), _p(ws.final_mask), max(ws.mask_words, 1), None,
+                                            stream)
+        _lib.check(st, "slam_score_hypotheses(final)")
+        if dense:
+            # exclusive prefix sum of the supporter counts: device-side plumbing
+            torch.cumsum(ws.final_count.view(-1), 0, dtype=torch.int32, out=ws.inl_off)
+            ws.inl_off.sub_(ws.final_count.view(-1))
+        tb = ws.tb
+        st = self.lib.slam_build_inlier_tables(_p(ws.pair), ws.P, _p(c.rows), _p(c.count), ws.cap, _p(ws.final_mask),
+                                               max(ws.mask_words, 1), _p(tb.xL), _p(tb.yL), _p(tb.xR),
+                                               _p(ws.inl_off) if dense else None, _p(ws.inl_rows), _p(ws.inl_loc),
+                                               _p(ws.n_inl), stream)
+        _lib.check(st, "slam_build_inlier_tables")
+
+    def run(self, ws, Rt=None):
+        """Enqueue the whole front-end for the frame range on the current stream."""
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if ws.F == 0:
+            return ws
+        self.stereo_match(ws, stream)
+        self.triangulate(ws, stream)
+        if ws.P > 0:
+            self.temporal_match(ws, stream)
+            self.join(ws, stream)
+            if Rt is not None and ws.H > 0:
+                if Rt.dtype != torch.float64 or not Rt.is_contiguous() or Rt.numel() != ws.P * ws.H * 12:
+                    raise ValueError("Rt must be a contiguous float64 tensor of shape [P, H, 3, 4]")
+                self.score(ws, Rt, stream)
+                self.select(ws, Rt, stream)
+        return ws
+
+
+def consensus_to_host(ws):
+    """Copy the per-pair consensus tables back: list of dicts (rows [M,4], X [M,3], ...)."""
+    c = ws.cons
+    count = c.count.cpu().numpy()[:ws.P]
+    if (count > ws.cap).any():
+        raise _lib.SlamError("consensus table overflow: a pair produced more rows than cap")
+    rows = c.rows.cpu().numpy()
+    X, Y, Z = c.X.cpu().numpy(), c.Y.cpu().numpy(), c.Z.cpu().numpy()
+    uL, vL, uR, vR = (t.cpu().numpy() for t in (c.uL, c.vL, c.uR, c.vR))
+    out = []
+    for p in range(ws.P):
+        s = slice(p * ws.cap, p * ws.cap + int(count[p]))
+        out.append({"rows": rows[s], "X": np.stack([X[s], Y[s], Z[s]], axis=1), "uvL": np.stack([uL[s], vL[s]], axis=1),
+                    "uvR": np.stack([uR[s], vR[s]], axis=1)})
+    return out

@@ -182,6 +182,20 @@ class SyntheticSequence:
         return np.hstack([Rr, (tj - Rr @ ti)[:, None]])
 
 
+def rodrigues_batch(rv):
+    """[H,3] rotation vectors -> [H,3,3] matrices."""
+    rv = np.asarray(rv, dtype=np.float64)
+    th = np.linalg.norm(rv, axis=1)
+    safe = np.where(th < 1e-300, 1.0, th)
+    k = rv / safe[:, None]
+    Kx = np.zeros((rv.shape[0], 3, 3))
+    Kx[:, 0, 1], Kx[:, 0, 2] = -k[:, 2], k[:, 1]
+    Kx[:, 1, 0], Kx[:, 1, 2] = k[:, 2], -k[:, 0]
+    Kx[:, 2, 0], Kx[:, 2, 1] = -k[:, 1], k[:, 0]
+    s, c = np.sin(th)[:, None, None], (1 - np.cos(th))[:, None, None]
+    return np.eye(3)[None] + s * Kx + c * (Kx @ Kx)
+
+
 def seeded_hypotheses(Rt_gt, n_hyp, seed=SEED):
     """A fixed, seeded hypothesis set around a ground-truth relative pose:
     rotation-vector noise sigma in {1e-3, 1e-2, 5e-2} rad and translation noise
@@ -189,11 +203,10 @@ def seeded_hypotheses(Rt_gt, n_hyp, seed=SEED):
     rng = np.random.default_rng(seed)
     sr = np.array([1e-3, 1e-2, 5e-2])
     st = np.array([0.01, 0.1, 0.5])
+    h = np.arange(n_hyp)
+    rv = rng.normal(size=(n_hyp, 3)) * sr[h % 3][:, None]
+    tv = rng.normal(size=(n_hyp, 3)) * st[(h // 3) % 3][:, None]
     out = np.empty((n_hyp, 3, 4))
-    R0, t0 = Rt_gt[:, :3], Rt_gt[:, 3]
-    rv = rng.normal(size=(n_hyp, 3))
-    tv = rng.normal(size=(n_hyp, 3))
-    for h in range(n_hyp):
-        out[h, :, :3] = rodrigues(rv[h] * sr[h % 3]) @ R0
-        out[h, :, 3] = t0 + tv[h] * st[(h // 3) % 3]
+    out[:, :, :3] = rodrigues_batch(rv) @ Rt_gt[:, :3]
+    out[:, :, 3] = Rt_gt[:, 3] + tv
     return out

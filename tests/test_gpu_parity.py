@@ -266,7 +266,7 @@ def test_matched_triangulation_and_join(device):
     # temporal matching of pairs (0,1), (1,2) + join
     seg_t = ops.make_segments(offL[:-2], nL[:-1], offL[1:-1], nL[1:], offL[:-2], device)
     tidx, tdist, tkeep = ops.hamming_match(dL, dL, seg_t, max(nL), max(nL), 61, k=2, mode=1, thr=1.0)
-    pair = torch.tensor([[offL[p], nL[p], offL[p + 1], nL[p + 1], offL[p], offL[p + 1]] for p in range(2)],
+    pair = torch.tensor([[offL[p], nL[p], offL[p + 1], nL[p + 1], offL[p], offL[p + 1], offL[p], 0] for p in range(2)],
                         dtype=torch.int32, device=device)
     cap = max(nL)
     cons = ops.join_consensus(pair, max(nL), tidx, tkeep, smap, valid, X, Y, Z, xL, yL, xR, yR, cap)
@@ -314,10 +314,13 @@ def _gpu_score(device, Rt, k, tr, pts, thresh, want_masks=True, cap=None):
     n = len(X)
     cap = n if cap is None else cap
     padf = lambda a, dt: np.concatenate([a.astype(dt), np.zeros(cap - n, dt)])
-    out = ops.score_hypotheses(t(Rt), k, tr, t(padf(X, np.float64)), t(padf(Y, np.float64)), t(padf(Z, np.float64)),
-                               t(padf(uL, np.float32)), t(padf(vL, np.float32)), t(padf(uR, np.float32)),
-                               t(padf(vR, np.float32)), thresh=thresh, cap=cap, n_host=n, want_masks=want_masks)
+    args = (t(Rt), k, tr, t(padf(X, np.float64)), t(padf(Y, np.float64)), t(padf(Z, np.float64)),
+            t(padf(uL, np.float32)), t(padf(vL, np.float32)), t(padf(uR, np.float32)), t(padf(vR, np.float32)))
+    out = ops.score_hypotheses(*args, thresh=thresh, cap=cap, n_host=n, want_masks=want_masks, fast=False)
+    # the filtered fast path must give the very same counts as the plain evaluation
+    fast = ops.score_hypotheses(*args, thresh=thresh, cap=cap, n_host=n, want_masks=False, fast=True)
     torch.cuda.synchronize()
+    assert torch.equal(fast, out[0] if want_masks else out), "fast path disagrees with the exact kernel"
     return out
 
 
@@ -400,10 +403,11 @@ def test_score_batched_sets_device_counts(device):
                                         for c in cases])
     Rt = np.stack([c[3] for c in cases])
     n_dev = torch.tensor([len(c[2][0]) for c in cases], dtype=torch.int32, device=device)
-    counts, masks = ops.score_hypotheses(t(Rt), k, tr, t(cat(0, np.float64)), t(cat(1, np.float64)),
-                                         t(cat(2, np.float64)), t(cat(3, np.float32)), t(cat(4, np.float32)),
-                                         t(cat(5, np.float32)), t(cat(6, np.float32)), thresh=2.0, cap=cap,
-                                         n_dev=n_dev, want_masks=True)
+    args = (t(Rt), k, tr, t(cat(0, np.float64)), t(cat(1, np.float64)), t(cat(2, np.float64)),
+            t(cat(3, np.float32)), t(cat(4, np.float32)), t(cat(5, np.float32)), t(cat(6, np.float32)))
+    counts, masks = ops.score_hypotheses(*args, thresh=2.0, cap=cap, n_dev=n_dev, want_masks=True)
+    fast = ops.score_hypotheses(*args, thresh=2.0, cap=cap, n_dev=n_dev, fast=True)
+    assert torch.equal(fast, counts)
     words = (cap + 63) // 64
     for s, c in enumerate(cases):
         rc, rm = oracle.score_hypotheses(c[3], k, tr, *c[2], 2.0, want_masks=True)
@@ -426,3 +430,24 @@ def test_score_empty_and_tiny(device):
     counts = _gpu_score(device, Rt[:1] * 0 + np.hstack([np.eye(3), np.zeros((3, 1))]), k, tr, one, 2.0,
                         want_masks=False)
     assert counts.cpu().numpy().tolist() == [[1]]
+
+
+def test_score_fast_path_general_k_and_scale(device):
+    seq, rows, pts, Rt = _consensus_case(1500, 2000)
+    k, m1, m2 = read_cameras()
+    tr = m2[:, 3]
+    rc = oracle.score_hypotheses(Rt, k, tr, *pts, 2.0, threads=8)
+    counts = _gpu_score(device, Rt, k, tr, pts, 2.0, want_masks=False)
+    assert np.array_equal(counts.cpu().numpy()[0], rc)
+    # skewed intrinsics: not a pinhole pattern, the library must take the plain kernel
+    k2 = k.copy()
+    k2[0, 1] = 0.37
+    k2[2, 0] = 1e-6
+    rc2 = oracle.score_hypotheses(Rt[:300], k2, tr, *pts, 2.0, threads=8)
+    counts2 = _gpu_score(device, Rt[:300], k2, tr, pts, 2.0, want_masks=False)
+    assert np.array_equal(counts2.cpu().numpy()[0], rc2)
+    # other thresholds, including sub-pixel ones where most evaluations sit near the band
+    for thresh in (0.05, 0.4, 1.0, 3.5, 50.0):
+        rc3 = oracle.score_hypotheses(Rt[:500], k, tr, *pts, thresh, threads=8)
+        c3 = _gpu_score(device, Rt[:500], k, tr, pts, thresh, want_masks=False)
+        assert np.array_equal(c3.cpu().numpy()[0], rc3), thresh
