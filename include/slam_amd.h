@@ -95,6 +95,19 @@ int slam_hamming_knn2(const uint8_t *q_dev, const uint8_t *t_dev,
                       int32_t *out_idx_dev, int32_t *out_dist_dev, void *stream);
 
 /*
+ * The two match filters on their own, for callers that already hold match lists.
+ * slam_ratio_filter replaces Matcher.apply_threshold / apply_thresholds
+ * (models/Matcher.py:148-160,178-184): idx, dist [n,2] int32 dev as written by
+ * slam_hamming_match; keep[i] = both neighbours present && (double)d0 < thr*(double)d1.
+ * slam_row_filter replaces _rectified_stereo_classifier (utils/utils.py:89-100):
+ * y1, y2 [n] float32 dev, already gathered per match; keep[i] = |y1-y2| <= thr in fp64.
+ */
+int slam_ratio_filter(const int32_t *idx_dev, const int32_t *dist_dev, int n,
+                      double thr, uint8_t *keep_dev, void *stream);
+int slam_row_filter(const float *y1_dev, const float *y2_dev, int n, double thr,
+                    uint8_t *keep_dev, void *stream);
+
+/*
  * Linear (DLT) triangulation of n stereo correspondences.
  * Replaces: least_squares (utils/utils.py:527-560) as driven per point by
  * get_3d_points_cloud (utils/utils.py:318-335).
@@ -184,7 +197,7 @@ int slam_join_consensus(const int32_t *pair_dev, int n_pairs, int max_nq,
  * A point supports iff both reprojection distances are < thresh (strict), all
  * in fp64 with one rounding per operation in the reference's order; no
  * cheirality test.
- * work_dev (nullable): caller-owned scratch of 6 * n_sets * cap doubles.  When it
+ * work_dev (nullable): caller-owned scratch of 10 * n_sets * cap doubles, 16-byte aligned.  When it
  * is given, masks_dev is NULL and K is a pinhole matrix [fx 0 cx; 0 fy cy; 0 0 1],
  * evaluations are first run through a division-free filter and only the ones
  * within a guard band of the threshold are evaluated in the reference's order;

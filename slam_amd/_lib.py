@@ -16,6 +16,8 @@ EXPORTS = (
     "slam_pack_descriptors",
     "slam_hamming_match",
     "slam_hamming_knn2",
+    "slam_ratio_filter",
+    "slam_row_filter",
     "slam_triangulate_dlt",
     "slam_triangulate_matched",
     "slam_join_consensus",
@@ -56,6 +58,10 @@ def load():
     lib.slam_hamming_match.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, vp]
     lib.slam_hamming_knn2.restype = ci
     lib.slam_hamming_knn2.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp]
+    lib.slam_ratio_filter.restype = ci
+    lib.slam_ratio_filter.argtypes = [vp, vp, ci, cd, vp, vp]
+    lib.slam_row_filter.restype = ci
+    lib.slam_row_filter.argtypes = [vp, vp, ci, cd, vp, vp]
     lib.slam_triangulate_dlt.restype = ci
     lib.slam_triangulate_dlt.argtypes = [vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp]
     lib.slam_triangulate_matched.restype = ci

@@ -227,6 +227,24 @@ __global__ void __launch_bounds__(256) pack_kernel(const uint8_t *src, int n, in
     }
 }
 
+// Stand-alone forms of the two match filters, for callers that hold the match lists.
+__global__ void __launch_bounds__(256) ratio_filter_kernel(const int32_t *__restrict__ idx,
+                                                           const int32_t *__restrict__ dist, int n, double thr,
+                                                           uint8_t *__restrict__ keep)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        keep[i] = (idx[2 * i] >= 0) && (idx[2 * i + 1] >= 0) && ((double)dist[2 * i] < thr * (double)dist[2 * i + 1]);
+}
+
+__global__ void __launch_bounds__(256) row_filter_kernel(const float *__restrict__ y1, const float *__restrict__ y2,
+                                                         int n, double thr, uint8_t *__restrict__ keep)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        keep[i] = fabs((double)y1[i] - (double)y2[i]) <= thr;
+}
+
 template <int W, int Q>
 int launch_knn(const KnnArgs &a, int batch, int max_nq, hipStream_t s)
 {
@@ -338,4 +356,31 @@ extern "C" int slam_hamming_knn2(const uint8_t *q, const uint8_t *t, const int32
 {
     return slam_hamming_match(q, t, seg, batch, max_nq, max_nt, desc_bytes, stride_bytes, k, 0, 0.0, nullptr, nullptr,
                               out_idx, out_dist, nullptr, stream);
+}
+
+extern "C" int slam_ratio_filter(const int32_t *idx, const int32_t *dist, int n, double thr, uint8_t *keep,
+                                 void *stream)
+{
+    if (n < 0)
+        return fail(SLAM_ERR_BAD_ARG, "slam_ratio_filter: n = %d", n);
+    if (n == 0)
+        return SLAM_OK;
+    if (!idx || !dist || !keep)
+        return fail(SLAM_ERR_BAD_ARG, "slam_ratio_filter: null buffer");
+    hipLaunchKernelGGL(ratio_filter_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, idx, dist, n, thr,
+                       keep);
+    return check_launch("slam_ratio_filter");
+}
+
+extern "C" int slam_row_filter(const float *y1, const float *y2, int n, double thr, uint8_t *keep, void *stream)
+{
+    if (n < 0)
+        return fail(SLAM_ERR_BAD_ARG, "slam_row_filter: n = %d", n);
+    if (n == 0)
+        return SLAM_OK;
+    if (!y1 || !y2 || !keep)
+        return fail(SLAM_ERR_BAD_ARG, "slam_row_filter: null buffer");
+    hipLaunchKernelGGL(row_filter_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, y1, y2, n, thr,
+                       keep);
+    return check_launch("slam_row_filter");
 }

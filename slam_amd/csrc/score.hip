@@ -78,8 +78,7 @@ struct ScoreArgs {
     unsigned long long *masks;
     int mask_words;
     int blocks_per_set;
-    double *work;      // [6][n_sets*cap]: a, b, ar, br, A, kappa (fast path only)
-    size_t wstride;    // n_sets*cap
+    double *work;      // [n_sets*cap][10] point records (fast path only)
     double trmax;      // max |t_right[i]|
 };
 
@@ -150,6 +149,8 @@ __global__ void __launch_bounds__(256) clear_mask_tail_kernel(unsigned long long
 }
 
 // ---- fast path ---------------------------------------------------------------
+constexpr int SCORE_REC = 10;  // doubles per point record: X Y Z a b ar br A kappa pad
+
 // Per-point quantities the filter needs, computed once per call instead of once per
 // hypothesis: pixel offsets from the principal point, the magnitude A = |X|+|Y|+|Z|
 // that bounds every partial sum of Rt @ [X,1], and the guard band kappa.
@@ -159,18 +160,19 @@ __global__ void __launch_bounds__(256) score_prep_kernel(const ScoreArgs a, int 
     const double fx = a.K.m[0], fy = a.K.m[4], cx = a.K.m[2], cy = a.K.m[5];
     for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
         const double uL = (double)a.uL[o], vL = (double)a.vL[o], uR = (double)a.uR[o], vR = (double)a.vR[o];
-        a.work[0 * a.wstride + o] = uL - cx;
-        a.work[1 * a.wstride + o] = vL - cy;
-        a.work[2 * a.wstride + o] = uR - cx;
-        a.work[3 * a.wstride + o] = vR - cy;
-        a.work[4 * a.wstride + o] = (fabs(a.X[o]) + fabs(a.Y[o])) + fabs(a.Z[o]);
+        const double X = a.X[o], Y = a.Y[o], Z = a.Z[o];
         const double mag = fabs(fx) + fabs(fy) + fabs(cx) + fabs(cy) + fabs(uL) + fabs(vL) + fabs(uR) + fabs(vR) +
                            fabs(a.thresh);
         // 2^-25 * mag / thresh + 2^-26; thresh <= 0 or NaN gives inf/NaN -> every lane takes the exact path
         double kappa = 2.98023223876953125e-8 * (mag / a.thresh) + 1.490116119384765625e-8;
         if (!(a.thresh > 0.0) || !(kappa < 0.25))
             kappa = __builtin_inf();
-        a.work[5 * a.wstride + o] = kappa;
+        double2 *rec = reinterpret_cast<double2 *>(a.work + SCORE_REC * o);
+        rec[0] = make_double2(X, Y);
+        rec[1] = make_double2(Z, uL - cx);
+        rec[2] = make_double2(vL - cy, uR - cx);
+        rec[3] = make_double2(vR - cy, (fabs(X) + fabs(Y)) + fabs(Z));
+        rec[4] = make_double2(kappa, 0.0);
     }
 }
 
@@ -210,19 +212,24 @@ __global__ void __launch_bounds__(256) score_fast_kernel(const ScoreArgs a)
     const double fx = a.K.m[0], fy = a.K.m[4];
     const double t0 = a.tr.v[0], t1 = a.tr.v[1], t2 = a.tr.v[2];
     const double thr = a.thresh;
-    const double *__restrict__ gX = a.X + pbase;
-    const double *__restrict__ gY = a.Y + pbase;
-    const double *__restrict__ gZ = a.Z + pbase;
-    const double *__restrict__ wa = a.work + 0 * a.wstride + pbase;
-    const double *__restrict__ wb = a.work + 1 * a.wstride + pbase;
-    const double *__restrict__ war = a.work + 2 * a.wstride + pbase;
-    const double *__restrict__ wbr = a.work + 3 * a.wstride + pbase;
-    const double *__restrict__ wA = a.work + 4 * a.wstride + pbase;
-    const double *__restrict__ wk = a.work + 5 * a.wstride + pbase;
+    const double *__restrict__ recs = a.work + SCORE_REC * pbase;
     int cnt = 0;
+    // One record per point, read through the scalar cache one iteration ahead.
+    double nx[SCORE_REC - 1];
+#pragma unroll
+    for (int c = 0; c < SCORE_REC - 1; ++c)
+        nx[c] = n > 0 ? recs[c] : 0.0;
     for (int i = 0; i < n; ++i) {
-        const double X = gX[i], Y = gY[i], Z = gZ[i];
-        const double pa = wa[i], pb = wb[i], par = war[i], pbr = wbr[i], A = wA[i], kap = wk[i];
+        double cur[SCORE_REC - 1];
+#pragma unroll
+        for (int c = 0; c < SCORE_REC - 1; ++c)
+            cur[c] = nx[c];
+        const int inext = min(i + 1, n - 1);
+#pragma unroll
+        for (int c = 0; c < SCORE_REC - 1; ++c)
+            nx[c] = recs[(size_t)SCORE_REC * inext + c];
+        const double X = cur[0], Y = cur[1], Z = cur[2];
+        const double pa = cur[3], pb = cur[4], par = cur[5], pbr = cur[6], A = cur[7], kap = cur[8];
         // filter: fused arithmetic, no division, no square root
         const double L0 = __builtin_fma(rt[0], X, __builtin_fma(rt[1], Y, __builtin_fma(rt[2], Z, rt[3])));
         const double L1 = __builtin_fma(rt[4], X, __builtin_fma(rt[5], Y, __builtin_fma(rt[6], Z, rt[7])));
@@ -278,8 +285,8 @@ extern "C" int slam_score_hypotheses(const double *Rt, int n_sets, int H, const 
     if (masks && mask_words < (cap + 63) / 64)
         return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: mask_words %d < ceil(cap/64) = %d", mask_words,
                     (cap + 63) / 64);
-    if (reinterpret_cast<uintptr_t>(Rt) & 15)
-        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: Rt must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(Rt) | reinterpret_cast<uintptr_t>(work)) & 15)
+        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: Rt and work must be 16-byte aligned");
     ScoreArgs a;
     a.Rt = Rt;
     a.H = H;
@@ -306,7 +313,6 @@ extern "C" int slam_score_hypotheses(const double *Rt, int n_sets, int H, const 
     a.masks = reinterpret_cast<unsigned long long *>(masks);
     a.mask_words = mask_words;
     a.work = work;
-    a.wstride = (size_t)n_sets * cap;
     hipStream_t s = (hipStream_t)stream;
 
     // The filter is written for the pinhole pattern K = [fx 0 cx; 0 fy cy; 0 0 1]

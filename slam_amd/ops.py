@@ -106,6 +106,28 @@ def hamming_knn2(q, t, seg, max_nq, max_nt, desc_bytes, k=2, n_rows=None):
     return idx, dist
 
 
+def ratio_filter(idx, dist, thr):
+    """keep [n] u8 for match tables idx/dist [n,2] i32 (slam_ratio_filter)."""
+    lib = _lib.load()
+    n = idx.shape[0]
+    keep = torch.zeros(n, dtype=torch.uint8, device=idx.device)
+    st = lib.slam_ratio_filter(_dev(idx, torch.int32, "idx"), _dev(dist, torch.int32, "dist"), n, float(thr),
+                               ctypes.c_void_p(keep.data_ptr()), _stream())
+    _lib.check(st, "slam_ratio_filter")
+    return keep
+
+
+def row_filter(y1, y2, thr):
+    """keep [n] u8 = |y1 - y2| <= thr in fp64 for paired float32 rows (slam_row_filter)."""
+    lib = _lib.load()
+    n = y1.shape[0]
+    keep = torch.zeros(n, dtype=torch.uint8, device=y1.device)
+    st = lib.slam_row_filter(_dev(y1, torch.float32, "y1"), _dev(y2, torch.float32, "y2"), n, float(thr),
+                             ctypes.c_void_p(keep.data_ptr()), _stream())
+    _lib.check(st, "slam_row_filter")
+    return keep
+
+
 def triangulate_dlt(P, Q, x1, y1, x2, y2):
     """DLT triangulation of n correspondences -> (X, Y, Z f64 [n], valid u8 [n])."""
     lib = _lib.load()
@@ -199,7 +221,7 @@ def score_hypotheses(Rt, K, t_right, X, Y, Z, uL, vL, uR, vR, thresh=2.0, cap=No
     Rt: [n_sets, H, 3, 4] (or [H,3,4] for one set) f64.  Points: flat SoA with set s
     at [s*cap, s*cap+n_s).  Returns counts [n_sets,H] i32 (and masks [n_sets,H,words] as
     int64 bit patterns when want_masks).  `fast` lets the library use its filtered path
-    (needs a scratch tensor `work` of 6*n_sets*cap doubles, allocated here if absent);
+    (needs a scratch tensor `work` of 10*n_sets*cap doubles, allocated here if absent);
     counts are identical with fast=False.
     """
     lib = _lib.load()
@@ -218,7 +240,7 @@ def score_hypotheses(Rt, K, t_right, X, Y, Z, uL, vL, uR, vR, thresh=2.0, cap=No
     masks = torch.zeros((n_sets, H, max(words, 1)), dtype=torch.int64, device=dev) if want_masks else None
     null = ctypes.c_void_p(0)
     if fast and not want_masks and work is None:
-        work = torch.empty(6 * max(n_sets * cap, 1), dtype=torch.float64, device=dev)
+        work = torch.empty(10 * max(n_sets * cap, 1), dtype=torch.float64, device=dev)
     st = lib.slam_score_hypotheses(
         _dev(Rt, torch.float64, "Rt"), n_sets, H, pK, pt, _dev(X, torch.float64, "X"), _dev(Y, torch.float64, "Y"),
         _dev(Z, torch.float64, "Z"), _dev(uL, torch.float32, "uL"), _dev(vL, torch.float32, "vL"),

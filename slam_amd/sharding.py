@@ -83,13 +83,14 @@ class TableGather:
         return res
 
 
-def chain_poses(rel_poses):
+def chain_poses(rel_poses, first=None):
     """Global extrinsics and camera centres from relative poses, as the reference
     composes them (utils/utils.py:283-288): R' = R @ R_prev, t' = R @ t_prev + t,
-    centre = -R'^T t'.  rel_poses: [P,3,4].  Returns ([P+1,3,4], [P+1,3])."""
+    centre = -R'^T t'.  rel_poses: [P,3,4]; first: extrinsic of frame 0 (the reference
+    starts at M1, utils/utils.py:244-245; default [I|0]).  Returns ([P+1,3,4], [P+1,3])."""
     n = rel_poses.shape[0] + 1
     ex = np.zeros((n, 3, 4))
-    ex[0] = np.hstack([np.eye(3), np.zeros((3, 1))])
+    ex[0] = np.hstack([np.eye(3), np.zeros((3, 1))]) if first is None else first
     cam = np.zeros((n, 3))
     for i in range(n - 1):
         Rt = rel_poses[i]

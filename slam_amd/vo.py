@@ -1,0 +1,60 @@
+"""Visual odometry over a frame range with the batched GPU front-end.
+
+Produces what the reference's frame loop produces (utils/utils.py:236-294) -- camera
+positions and a filled track database -- but runs stereo matching, triangulation,
+temporal matching and the four-image join for the WHOLE range in four kernel launches
+(slam_amd.pipeline), and only then walks the pairs in order for PnP-RANSAC, whose use of
+the process-global random stream makes it sequential by definition.  Given the same
+features and the same `random` state it returns exactly what
+slam_amd.frontend.track_camera_for_many_images returns.
+"""
+import numpy as np
+import torch
+
+from . import frontend, pipeline
+from .constants import PIXEL_THRESH, STEREO_ROW_THRESH, VO_MAX_ITERATIONS
+from .sharding import chain_poses
+from .track_database import TrackDatabase
+
+
+def front_end_tables(frames, cameras=None, thresh=1, device=None):
+    """Stages 1-4 for all frames on the GPU; returns (workspace, list of per-pair host
+    dicts with rows [M,4], X [M,3], uvL [M,2], uvR [M,2])."""
+    k, m1, m2 = cameras if cameras is not None else frontend.read_cameras()
+    if device is None:
+        device = frontend._default_device()
+    fe = pipeline.FrontEnd(k, m1, m2, row_thresh=STEREO_ROW_THRESH, ratio_thresh=thresh, pix_thresh=PIXEL_THRESH)
+    tb = pipeline.FrameTables.from_frames(frames, device)
+    ws = fe.prepare(tb, n_hyp=0)
+    fe.run(ws)
+    torch.cuda.synchronize()
+    return ws, pipeline.consensus_to_host(ws)
+
+
+def track_camera_batched(frames, cameras=None, thresh=1, max_iterations=VO_MAX_ITERATIONS, device=None):
+    """(camera_positions [F,3], TrackDatabase) for precomputed features `frames`
+    (objects with kpL/kpR [N,2] float32 and descL/descR [N,D] uint8)."""
+    k, m1, m2 = cameras if cameras is not None else frontend.read_cameras()
+    ws, pairs = front_end_tables(frames, (k, m1, m2), thresh=thresh, device=device)
+    db = TrackDatabase()
+    rel = []
+    for p, tab in enumerate(pairs):
+        Rt, ratio, mask = frontend.ransac_on_arrays(tab["X"], tab["uvL"], tab["uvR"], k, m2, thresh=PIXEL_THRESH,
+                                                    max_iterations=max_iterations)
+        assert mask is not None, f"RANSAC Couldn't find a transformation from frame {p} to frame {p + 1}..."
+        sel = np.flatnonzero(mask)
+        rows = tab["rows"][sel]
+        f0, f1 = frames[p], frames[p + 1]
+        loc = np.stack([f0.kpL[rows[:, 0], 0], f0.kpR[rows[:, 1], 0], f0.kpL[rows[:, 0], 1],
+                        f1.kpL[rows[:, 2], 0], f1.kpR[rows[:, 3], 0], f1.kpL[rows[:, 2], 1]], axis=1) \
+            if len(sel) else np.zeros((0, 6), np.float32)
+        db.update_tracks_from_tables(p, rows, loc)
+        db.add_inliers_ratio(p, ratio)
+        db.add_num_matches(p, num_matches=np.sum(mask))
+        rel.append(Rt)
+    n = len(frames)
+    ex, cam = chain_poses(np.stack(rel), first=m1) if rel else (np.zeros((n, 3, 4)), np.zeros((n, 3)))
+    if rel:
+        db.set_ex_camera_positions(cam)
+        db.set_ex_matrices(ex)
+    return cam, db
