@@ -49,6 +49,9 @@ class TableGather:
 
     def gather(self, n_inl, rows, loc, pose, n_cons):
         world, rank = self.world, self.rank
+        if world > 1 and n_inl.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal on a box without one GPU per rank: stage through host memory
+            n_inl, rows, loc, pose, n_cons = (t.cpu() for t in (n_inl, rows, loc, pose, n_cons))
         dev = n_inl.device
         if world == 1:
             T = int(n_inl.sum().item())
