@@ -15,7 +15,7 @@
 //                     wave-uniform so point data arrives through scalar loads and
 //                     costs no VALU.  Each evaluation first runs a division- and
 //                     sqrt-free *filter* in fused fp64 arithmetic:
-//                         dx = (u-cx)*hz - fx*L0,  dy = (v-cy)*hz - fy*L1,
+//                         dx = u*hz - hx,  dy = v*hz - hy,   (hx,hy,hz) = (K @ Rt) @ [X,1]
 //                         s = dx^2 + dy^2   versus   T = (thresh*hz)^2
 //                     (the reference's test multiplied through by hz^2).  With a
 //                     per-point relative guard band kappa the filter answers "in" if
@@ -149,11 +149,11 @@ __global__ void __launch_bounds__(256) clear_mask_tail_kernel(unsigned long long
 }
 
 // ---- fast path ---------------------------------------------------------------
-constexpr int SCORE_REC = 10;  // doubles per point record: X Y Z a b ar br A kappa pad
+constexpr int SCORE_REC = 10;  // doubles per point record: X Y Z uL vL uR vR A kq kq2
 
 // Per-point quantities the filter needs, computed once per call instead of once per
-// hypothesis: pixel offsets from the principal point, the magnitude A = |X|+|Y|+|Z|
-// that bounds every partial sum of Rt @ [X,1], and the guard band kappa.
+// hypothesis: coordinates widened to fp64, the magnitude A = |X|+|Y|+|Z| that bounds
+// every partial sum of Rt @ [X,1], and the guard band folded with the threshold.
 __global__ void __launch_bounds__(256) score_prep_kernel(const ScoreArgs a, int n_sets)
 {
     const size_t total = (size_t)n_sets * a.cap;
@@ -163,19 +163,30 @@ __global__ void __launch_bounds__(256) score_prep_kernel(const ScoreArgs a, int 
         const double X = a.X[o], Y = a.Y[o], Z = a.Z[o];
         const double mag = fabs(fx) + fabs(fy) + fabs(cx) + fabs(cy) + fabs(uL) + fabs(vL) + fabs(uR) + fabs(vR) +
                            fabs(a.thresh);
-        // 2^-25 * mag / thresh + 2^-26; thresh <= 0 or NaN gives inf/NaN -> every lane takes the exact path
-        double kappa = 2.98023223876953125e-8 * (mag / a.thresh) + 1.490116119384765625e-8;
-        if (!(a.thresh > 0.0) || !(kappa < 0.25))
-            kappa = __builtin_inf();
+        // kappa = 2^-25 * mag / thresh + 2^-26; thresh <= 0, NaN or a band that is not small
+        // gives kp = inf, which sends every evaluation of the point to the exact path
+        const double kappa = 2.98023223876953125e-8 * (mag / a.thresh) + 1.490116119384765625e-8;
+        // the band as two per-point factors with the threshold folded in:
+        //   "in"  <=>  s * kq  < hz^2      (kq  = (1+kappa)/(1-kappa) / thresh^2)
+        //   "out" <=>  s > hz^2 * kq2      (kq2 = (1+kappa)/(1-kappa) * thresh^2)
+        const double kp = (1.0 + kappa) / (1.0 - kappa);
+        const double t2 = a.thresh * a.thresh;
+        double kq = kp / t2, kq2 = kp * t2;
+        if (!(a.thresh > 0.0) || !(kappa < 0.25) || !(kq < __builtin_inf()) || !(kq2 < __builtin_inf()) ||
+            !(kq > 0.0) || !(kq2 > 0.0))
+            kq = kq2 = __builtin_inf();
         double2 *rec = reinterpret_cast<double2 *>(a.work + SCORE_REC * o);
         rec[0] = make_double2(X, Y);
-        rec[1] = make_double2(Z, uL - cx);
-        rec[2] = make_double2(vL - cy, uR - cx);
-        rec[3] = make_double2(vR - cy, (fabs(X) + fabs(Y)) + fabs(Z));
-        rec[4] = make_double2(kappa, 0.0);
+        rec[1] = make_double2(Z, uL);
+        rec[2] = make_double2(vL, uR);
+        rec[3] = make_double2(vR, (fabs(X) + fabs(Y)) + fabs(Z));
+        rec[4] = make_double2(kq, kq2);
     }
 }
 
+// RECT: t_right[1] == t_right[2] == 0 (rectified stereo, the KITTI case): both cameras
+// share hz, hy and the threshold term, and one max() serves both verdicts.
+template <bool RECT>
 __global__ void __launch_bounds__(256) score_fast_kernel(const ScoreArgs a)
 {
     const int set = blockIdx.x / a.blocks_per_set;
@@ -198,57 +209,77 @@ __global__ void __launch_bounds__(256) score_fast_kernel(const ScoreArgs a)
 #pragma unroll
         for (int c = 0; c < 3; ++c)
             Bh = fmax(Bh, fabs(rt[4 * r + c]));
-    const double Tm = fmax(fmax(fabs(rt[3]), fabs(rt[7])), fabs(rt[11])) + a.trmax;
-    // NaN anywhere in the pose must reach the exact path: fmax drops NaNs, so test it here
+    // 2^-20 * (magnitude bound of the terms summed into hz): hz is trusted only above it
+    const double Bs = Bh * 9.5367431640625e-07;
+    const double Ts = (fmax(fmax(fabs(rt[3]), fabs(rt[7])), fabs(rt[11])) + a.trmax) * 9.5367431640625e-07;
+    // NaN/Inf anywhere in the pose must reach the exact path (fmax drops NaNs)
     bool pose_ok = true;
 #pragma unroll
     for (int c = 0; c < 12; ++c)
         pose_ok = pose_ok && (fabs(rt[c]) < __builtin_inf());
 
+    // homogeneous pixel rows of K @ Rt for the pinhole K: hx = fx*L0 + cx*L2, hy = fy*L1 + cy*L2, hz = L2
+    const double fx = a.K.m[0], fy = a.K.m[4], cx = a.K.m[2], cy = a.K.m[5];
+    double px[4], py[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        px[c] = __builtin_fma(fx, rt[c], cx * rt[8 + c]);
+        py[c] = __builtin_fma(fy, rt[4 + c], cy * rt[8 + c]);
+    }
+    // the right camera adds a constant to each homogeneous coordinate
+    const double cr0 = __builtin_fma(fx, a.tr.v[0], cx * a.tr.v[2]);
+    const double cr1 = __builtin_fma(fy, a.tr.v[1], cy * a.tr.v[2]);
+    const double cr2 = a.tr.v[2];
+    const double thr = a.thresh;
+
     int n = a.n_dev ? a.n_dev[set] : a.n_host;
     n = min(max(n, 0), a.cap);
     n = __builtin_amdgcn_readfirstlane(n);
     const size_t pbase = (size_t)set * a.cap;
-    const double fx = a.K.m[0], fy = a.K.m[4];
-    const double t0 = a.tr.v[0], t1 = a.tr.v[1], t2 = a.tr.v[2];
-    const double thr = a.thresh;
     const double *__restrict__ recs = a.work + SCORE_REC * pbase;
     int cnt = 0;
     // One record per point, read through the scalar cache one iteration ahead.
-    double nx[SCORE_REC - 1];
+    double nx[SCORE_REC];
 #pragma unroll
-    for (int c = 0; c < SCORE_REC - 1; ++c)
+    for (int c = 0; c < SCORE_REC; ++c)
         nx[c] = n > 0 ? recs[c] : 0.0;
     for (int i = 0; i < n; ++i) {
-        double cur[SCORE_REC - 1];
+        double cur[SCORE_REC];
 #pragma unroll
-        for (int c = 0; c < SCORE_REC - 1; ++c)
+        for (int c = 0; c < SCORE_REC; ++c)
             cur[c] = nx[c];
         const int inext = min(i + 1, n - 1);
 #pragma unroll
-        for (int c = 0; c < SCORE_REC - 1; ++c)
+        for (int c = 0; c < SCORE_REC; ++c)
             nx[c] = recs[(size_t)SCORE_REC * inext + c];
         const double X = cur[0], Y = cur[1], Z = cur[2];
-        const double pa = cur[3], pb = cur[4], par = cur[5], pbr = cur[6], A = cur[7], kap = cur[8];
+        const double uL = cur[3], vL = cur[4], uR = cur[5], vR = cur[6], A = cur[7], kq = cur[8], kq2 = cur[9];
         // filter: fused arithmetic, no division, no square root
-        const double L0 = __builtin_fma(rt[0], X, __builtin_fma(rt[1], Y, __builtin_fma(rt[2], Z, rt[3])));
-        const double L1 = __builtin_fma(rt[4], X, __builtin_fma(rt[5], Y, __builtin_fma(rt[6], Z, rt[7])));
-        const double L2 = __builtin_fma(rt[8], X, __builtin_fma(rt[9], Y, __builtin_fma(rt[10], Z, rt[11])));
-        const double R0 = L0 + t0, R1 = L1 + t1, R2 = L2 + t2;
-        const double dxl = __builtin_fma(pa, L2, -(fx * L0));
-        const double dyl = __builtin_fma(pb, L2, -(fy * L1));
-        const double dxr = __builtin_fma(par, R2, -(fx * R0));
-        const double dyr = __builtin_fma(pbr, R2, -(fy * R1));
+        const double hx = __builtin_fma(px[0], X, __builtin_fma(px[1], Y, __builtin_fma(px[2], Z, px[3])));
+        const double hy = __builtin_fma(py[0], X, __builtin_fma(py[1], Y, __builtin_fma(py[2], Z, py[3])));
+        const double hz = __builtin_fma(rt[8], X, __builtin_fma(rt[9], Y, __builtin_fma(rt[10], Z, rt[11])));
+        const double hzr = RECT ? hz : hz + cr2;
+        const double hyr = RECT ? hy : hy + cr1;
+        const double dxl = __builtin_fma(uL, hz, -hx);
+        const double dyl = __builtin_fma(vL, hz, -hy);
+        const double dxr = __builtin_fma(uR, hzr, -(hx + cr0));
+        const double dyr = __builtin_fma(vR, hzr, -hyr);
         const double sl = __builtin_fma(dxl, dxl, dyl * dyl);
         const double sr = __builtin_fma(dxr, dxr, dyr * dyr);
-        const double tl = thr * L2, tr_ = thr * R2;
-        const double Tl = tl * tl, Tr = tr_ * tr_;
-        const double ml = kap * (sl + Tl), mr = kap * (sr + Tr);
-        const double dl = sl - Tl, dr = sr - Tr;
-        const double S = __builtin_fma(Bh, A, Tm) * 9.5367431640625e-07;  // 2^-20 * magnitude of the summed terms
-        const bool tiny = !(fabs(L2) > S) || !(fabs(R2) > S);
-        const bool sure_in = (dl < -ml) && (dr < -mr);
-        const bool sure_out = (dl > ml) || (dr > mr);
+        const double S = __builtin_fma(Bs, A, Ts);
+        const double hz2 = hz * hz;
+        bool tiny, sure_in, sure_out;
+        if (RECT) {
+            const double m = fmax(sl, sr);   // NaN-dropping max: a NaN side is caught by the tests below
+            tiny = !(fabs(hz) > S) || __builtin_isunordered(sl, sr);
+            sure_in = m * kq < hz2;
+            sure_out = m > hz2 * kq2;
+        } else {
+            const double hzr2 = hzr * hzr;
+            tiny = !(fabs(hz) > S) || !(fabs(hzr) > S);
+            sure_in = (sl * kq < hz2) && (sr * kq < hzr2);
+            sure_out = (sl > hz2 * kq2) || (sr > hzr2 * kq2);
+        }
         bool s = sure_in;
         if (tiny || !pose_ok || !(sure_in || sure_out)) {
             const size_t o = pbase + i;
@@ -330,7 +361,10 @@ extern "C" int slam_score_hypotheses(const double *Rt, int n_sets, int H, const 
         const long long blocks = (long long)n_sets * a.blocks_per_set;
         if (blocks > 0x7FFFFFFFLL)
             return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: grid too large");
-        hipLaunchKernelGGL(score_fast_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        if (t_right[1] == 0.0 && t_right[2] == 0.0)
+            hipLaunchKernelGGL(score_fast_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(score_fast_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
         return check_launch("slam_score_hypotheses(fast)");
     }
 

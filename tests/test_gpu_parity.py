@@ -446,6 +446,11 @@ def test_score_fast_path_general_k_and_scale(device):
     rc2 = oracle.score_hypotheses(Rt[:300], k2, tr, *pts, 2.0, threads=8)
     counts2 = _gpu_score(device, Rt[:300], k2, tr, pts, 2.0, want_masks=False)
     assert np.array_equal(counts2.cpu().numpy()[0], rc2)
+    # a right camera that is not purely sideways (t_right[1], t_right[2] != 0): the other filter variant
+    tr2 = np.array([tr[0], 0.013, -0.021])
+    rc4 = oracle.score_hypotheses(Rt[:700], k, tr2, *pts, 2.0, threads=8)
+    c4 = _gpu_score(device, Rt[:700], k, tr2, pts, 2.0, want_masks=False)
+    assert np.array_equal(c4.cpu().numpy()[0], rc4) and rc4.max() > 0
     # other thresholds, including sub-pixel ones where most evaluations sit near the band
     for thresh in (0.05, 0.4, 1.0, 3.5, 50.0):
         rc3 = oracle.score_hypotheses(Rt[:500], k, tr, *pts, thresh, threads=8)
