@@ -78,7 +78,8 @@ struct ScoreArgs {
     unsigned long long *masks;
     int mask_words;
     int blocks_per_set;
-    double *work;      // [n_sets*cap][10] point records (fast path only)
+    double *work;      // point records + per-set bounds (fast path only)
+    size_t n_rec;      // n_sets * cap
     double trmax;      // max |t_right[i]|
 };
 
@@ -149,38 +150,61 @@ __global__ void __launch_bounds__(256) clear_mask_tail_kernel(unsigned long long
 }
 
 // ---- fast path ---------------------------------------------------------------
-constexpr int SCORE_REC = 10;  // doubles per point record: X Y Z uL vL uR vR A kq kq2
+// Workspace layout (doubles): [n_sets*cap][8] point records  X Y Z uL vL uR vR pad,
+// then [n_sets][2] per-set bounds kept as the bit patterns of non-negative doubles:
+// Amax = max(|X|+|Y|+|Z|) and Umax = max(|uL|+|vL|+|uR|+|vR|) over the set's points.
+constexpr int SCORE_REC = 8;
 
-// Per-point quantities the filter needs, computed once per call instead of once per
-// hypothesis: coordinates widened to fp64, the magnitude A = |X|+|Y|+|Z| that bounds
-// every partial sum of Rt @ [X,1], and the guard band folded with the threshold.
-__global__ void __launch_bounds__(256) score_prep_kernel(const ScoreArgs a, int n_sets)
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 {
-    const size_t total = (size_t)n_sets * a.cap;
-    const double fx = a.K.m[0], fy = a.K.m[4], cx = a.K.m[2], cy = a.K.m[5];
-    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(v, off);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// Widens the point data to fp64 records and reduces the two per-set magnitude bounds
+// (non-negative doubles order like their bit patterns, so an integer atomic max does it).
+// A NaN magnitude maps to the largest pattern and ends up disabling the filter for the set.
+__global__ void __launch_bounds__(256) score_prep_kernel(const ScoreArgs a, int chunks_per_set)
+{
+    __shared__ unsigned long long red[2][4];
+    const int set = blockIdx.x / chunks_per_set;
+    const int chunk = blockIdx.x - set * chunks_per_set;
+    int n = a.n_dev ? a.n_dev[set] : a.n_host;
+    n = min(max(n, 0), a.cap);
+    const int i = chunk * 256 + threadIdx.x;
+    unsigned long long am = 0ull, um = 0ull;
+    if (i < n) {
+        const size_t o = (size_t)set * a.cap + i;
         const double uL = (double)a.uL[o], vL = (double)a.vL[o], uR = (double)a.uR[o], vR = (double)a.vR[o];
         const double X = a.X[o], Y = a.Y[o], Z = a.Z[o];
-        const double mag = fabs(fx) + fabs(fy) + fabs(cx) + fabs(cy) + fabs(uL) + fabs(vL) + fabs(uR) + fabs(vR) +
-                           fabs(a.thresh);
-        // kappa = 2^-25 * mag / thresh + 2^-26; thresh <= 0, NaN or a band that is not small
-        // gives kp = inf, which sends every evaluation of the point to the exact path
-        const double kappa = 2.98023223876953125e-8 * (mag / a.thresh) + 1.490116119384765625e-8;
-        // the band as two per-point factors with the threshold folded in:
-        //   "in"  <=>  s * kq  < hz^2      (kq  = (1+kappa)/(1-kappa) / thresh^2)
-        //   "out" <=>  s > hz^2 * kq2      (kq2 = (1+kappa)/(1-kappa) * thresh^2)
-        const double kp = (1.0 + kappa) / (1.0 - kappa);
-        const double t2 = a.thresh * a.thresh;
-        double kq = kp / t2, kq2 = kp * t2;
-        if (!(a.thresh > 0.0) || !(kappa < 0.25) || !(kq < __builtin_inf()) || !(kq2 < __builtin_inf()) ||
-            !(kq > 0.0) || !(kq2 > 0.0))
-            kq = kq2 = __builtin_inf();
         double2 *rec = reinterpret_cast<double2 *>(a.work + SCORE_REC * o);
         rec[0] = make_double2(X, Y);
         rec[1] = make_double2(Z, uL);
         rec[2] = make_double2(vL, uR);
-        rec[3] = make_double2(vR, (fabs(X) + fabs(Y)) + fabs(Z));
-        rec[4] = make_double2(kq, kq2);
+        rec[3] = make_double2(vR, 0.0);
+        const double A = (fabs(X) + fabs(Y)) + fabs(Z);
+        const double U = (fabs(uL) + fabs(vL)) + (fabs(uR) + fabs(vR));
+        am = (A == A) ? (unsigned long long)__double_as_longlong(A) : ~0ull;
+        um = (U == U) ? (unsigned long long)__double_as_longlong(U) : ~0ull;
+    }
+    am = wave_max_u64(am);
+    um = wave_max_u64(um);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = am;
+        red[1][threadIdx.x >> 6] = um;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        unsigned long long m = red[threadIdx.x][0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            m = red[threadIdx.x][w] > m ? red[threadIdx.x][w] : m;
+        unsigned long long *hdr = reinterpret_cast<unsigned long long *>(a.work + SCORE_REC * a.n_rec) + 2 * set;
+        atomicMax(hdr + threadIdx.x, m);
     }
 }
 
@@ -203,23 +227,36 @@ __global__ void __launch_bounds__(256) score_fast_kernel(const ScoreArgs a)
         rt[c] = v.x;
         rt[c + 1] = v.y;
     }
+    const double fx = a.K.m[0], fy = a.K.m[4], cx = a.K.m[2], cy = a.K.m[5];
+    const double thr = a.thresh;
+    const double *hdr = a.work + SCORE_REC * a.n_rec + 2 * set;
+    const double Amax = hdr[0], Umax = hdr[1];   // NaN patterns if any point of the set was NaN
+
     double Bh = 0.0;
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c)
             Bh = fmax(Bh, fabs(rt[4 * r + c]));
-    // 2^-20 * (magnitude bound of the terms summed into hz): hz is trusted only above it
-    const double Bs = Bh * 9.5367431640625e-07;
-    const double Ts = (fmax(fmax(fabs(rt[3]), fabs(rt[7])), fabs(rt[11])) + a.trmax) * 9.5367431640625e-07;
-    // NaN/Inf anywhere in the pose must reach the exact path (fmax drops NaNs)
-    bool pose_ok = true;
+    // hz is trusted only above 2^-20 * (magnitude bound of the terms it was summed from)
+    const double S = (Bh * Amax + (fmax(fmax(fabs(rt[3]), fabs(rt[7])), fabs(rt[11])) + a.trmax)) *
+                     9.5367431640625e-07;
+    // guard band: kappa = 2^-25 * mag / thresh + 2^-26, folded with the threshold into
+    //   "in"  <=>  s * kq  < hz^2      (kq  = (1+kappa)/(1-kappa) / thresh^2)
+    //   "out" <=>  s > hz^2 * kq2      (kq2 = (1+kappa)/(1-kappa) * thresh^2)
+    const double mag = fabs(fx) + fabs(fy) + fabs(cx) + fabs(cy) + Umax + fabs(thr);
+    const double kappa = 2.98023223876953125e-8 * (mag / thr) + 1.490116119384765625e-8;
+    const double kp = (1.0 + kappa) / (1.0 - kappa);
+    const double kq = kp / (thr * thr), kq2 = kp * (thr * thr);
+    // Anything that makes the filter unsafe sends every evaluation of this lane to supports():
+    // NaN/Inf in the pose (fmax drops NaNs) or the bounds, thresh <= 0 or NaN, a band that is not small.
+    bool filter_ok = (thr > 0.0) && (kappa < 0.25) && (kq > 0.0) && (kq < __builtin_inf()) && (kq2 > 0.0) &&
+                     (kq2 < __builtin_inf()) && (S < __builtin_inf());
 #pragma unroll
     for (int c = 0; c < 12; ++c)
-        pose_ok = pose_ok && (fabs(rt[c]) < __builtin_inf());
+        filter_ok = filter_ok && (fabs(rt[c]) < __builtin_inf());
 
     // homogeneous pixel rows of K @ Rt for the pinhole K: hx = fx*L0 + cx*L2, hy = fy*L1 + cy*L2, hz = L2
-    const double fx = a.K.m[0], fy = a.K.m[4], cx = a.K.m[2], cy = a.K.m[5];
     double px[4], py[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -230,30 +267,15 @@ __global__ void __launch_bounds__(256) score_fast_kernel(const ScoreArgs a)
     const double cr0 = __builtin_fma(fx, a.tr.v[0], cx * a.tr.v[2]);
     const double cr1 = __builtin_fma(fy, a.tr.v[1], cy * a.tr.v[2]);
     const double cr2 = a.tr.v[2];
-    const double thr = a.thresh;
 
     int n = a.n_dev ? a.n_dev[set] : a.n_host;
     n = min(max(n, 0), a.cap);
     n = __builtin_amdgcn_readfirstlane(n);
-    const size_t pbase = (size_t)set * a.cap;
-    const double *__restrict__ recs = a.work + SCORE_REC * pbase;
+    const double *__restrict__ recs = a.work + (size_t)SCORE_REC * ((size_t)set * a.cap);
     int cnt = 0;
-    // One record per point, read through the scalar cache one iteration ahead.
-    double nx[SCORE_REC];
-#pragma unroll
-    for (int c = 0; c < SCORE_REC; ++c)
-        nx[c] = n > 0 ? recs[c] : 0.0;
-    for (int i = 0; i < n; ++i) {
-        double cur[SCORE_REC];
-#pragma unroll
-        for (int c = 0; c < SCORE_REC; ++c)
-            cur[c] = nx[c];
-        const int inext = min(i + 1, n - 1);
-#pragma unroll
-        for (int c = 0; c < SCORE_REC; ++c)
-            nx[c] = recs[(size_t)SCORE_REC * inext + c];
-        const double X = cur[0], Y = cur[1], Z = cur[2];
-        const double uL = cur[3], vL = cur[4], uR = cur[5], vR = cur[6], A = cur[7], kq = cur[8], kq2 = cur[9];
+
+    auto eval = [&](const double (&p)[SCORE_REC]) {
+        const double X = p[0], Y = p[1], Z = p[2], uL = p[3], vL = p[4], uR = p[5], vR = p[6];
         // filter: fused arithmetic, no division, no square root
         const double hx = __builtin_fma(px[0], X, __builtin_fma(px[1], Y, __builtin_fma(px[2], Z, px[3])));
         const double hy = __builtin_fma(py[0], X, __builtin_fma(py[1], Y, __builtin_fma(py[2], Z, py[3])));
@@ -266,27 +288,56 @@ __global__ void __launch_bounds__(256) score_fast_kernel(const ScoreArgs a)
         const double dyr = __builtin_fma(vR, hzr, -hyr);
         const double sl = __builtin_fma(dxl, dxl, dyl * dyl);
         const double sr = __builtin_fma(dxr, dxr, dyr * dyr);
-        const double S = __builtin_fma(Bs, A, Ts);
         const double hz2 = hz * hz;
-        bool tiny, sure_in, sure_out;
+        bool unsafe, sure_in, sure_out;
         if (RECT) {
-            const double m = fmax(sl, sr);   // NaN-dropping max: a NaN side is caught by the tests below
-            tiny = !(fabs(hz) > S) || __builtin_isunordered(sl, sr);
+            const double m = fmax(sl, sr);   // drops a NaN operand: the unordered test below catches it
+            unsafe = !(fabs(hz) > S) || __builtin_isunordered(sl, sr);
             sure_in = m * kq < hz2;
             sure_out = m > hz2 * kq2;
         } else {
             const double hzr2 = hzr * hzr;
-            tiny = !(fabs(hz) > S) || !(fabs(hzr) > S);
+            unsafe = !(fabs(hz) > S) || !(fabs(hzr) > S);
             sure_in = (sl * kq < hz2) && (sr * kq < hzr2);
             sure_out = (sl > hz2 * kq2) || (sr > hzr2 * kq2);
         }
         bool s = sure_in;
-        if (tiny || !pose_ok || !(sure_in || sure_out)) {
-            const size_t o = pbase + i;
-            s = supports(rt, a.K, a.tr, X, Y, Z, (double)a.uL[o], (double)a.vL[o], (double)a.uR[o], (double)a.vR[o],
-                         thr);
-        }
+        if (unsafe || !filter_ok || !(sure_in || sure_out))
+            s = supports(rt, a.K, a.tr, X, Y, Z, uL, vL, uR, vR, thr);   // float32 -> fp64 widening is exact
         cnt += s ? 1 : 0;
+    };
+    auto load = [&](double (&p)[SCORE_REC], int i) {
+        const double *r = recs + (size_t)SCORE_REC * min(i, n - 1);
+#pragma unroll
+        for (int c = 0; c < SCORE_REC; ++c)
+            p[c] = r[c];
+    };
+
+    // Records arrive through the scalar cache (the loop is wave-uniform), two points per
+    // step and one step ahead: a scalar wait drains every outstanding scalar load, so the
+    // loads of the NEXT pair are issued right after the wait for the current one.
+    if (n > 0) {
+        double a0[SCORE_REC], a1[SCORE_REC], b0[SCORE_REC], b1[SCORE_REC];
+        load(a0, 0);
+        load(a1, 1);
+        int i = 0;
+        for (; i + 4 <= n; i += 4) {
+            load(b0, i + 2);
+            load(b1, i + 3);
+            eval(a0);
+            eval(a1);
+            load(a0, i + 4);
+            load(a1, i + 5);
+            eval(b0);
+            eval(b1);
+        }
+        for (; i < n; ++i) {
+            eval(a0);
+#pragma unroll
+            for (int c = 0; c < SCORE_REC; ++c)
+                a0[c] = a1[c];
+            load(a1, i + 2);
+        }
     }
     if (live)
         a.counts[(size_t)set * a.H + h] = cnt;
@@ -344,6 +395,7 @@ extern "C" int slam_score_hypotheses(const double *Rt, int n_sets, int H, const 
     a.masks = reinterpret_cast<unsigned long long *>(masks);
     a.mask_words = mask_words;
     a.work = work;
+    a.n_rec = 0;
     hipStream_t s = (hipStream_t)stream;
 
     // The filter is written for the pinhole pattern K = [fx 0 cx; 0 fy cy; 0 0 1]
@@ -354,9 +406,14 @@ extern "C" int slam_score_hypotheses(const double *Rt, int n_sets, int H, const 
     for (int i = 0; i < 3; ++i)
         pinhole = pinhole && (t_right[i] - t_right[i] == 0.0);
     if (work && !masks && pinhole && cap > 0) {
-        const size_t total = (size_t)n_sets * cap;
-        const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-        hipLaunchKernelGGL(score_prep_kernel, dim3(grid), dim3(256), 0, s, a, n_sets);
+        a.n_rec = (size_t)n_sets * cap;
+        hipError_t e = hipMemsetAsync(work + SCORE_REC * a.n_rec, 0, sizeof(double) * 2 * (size_t)n_sets, s);
+        if (e != hipSuccess)
+            return fail(SLAM_ERR_LAUNCH, "slam_score_hypotheses: %s", hipGetErrorString(e));
+        const int chunks = (cap + 255) / 256;
+        if ((long long)n_sets * chunks > 0x7FFFFFFFLL)
+            return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: grid too large");
+        hipLaunchKernelGGL(score_prep_kernel, dim3((unsigned)(n_sets * chunks)), dim3(256), 0, s, a, chunks);
         a.blocks_per_set = (H + 255) / 256;
         const long long blocks = (long long)n_sets * a.blocks_per_set;
         if (blocks > 0x7FFFFFFFLL)
