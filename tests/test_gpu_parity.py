@@ -23,6 +23,13 @@ def _rand_desc(rng, n, D):
 
 
 # --------------------------------------------------------------------------- knn
+@pytest.fixture(params=["mfma", "valu"], autouse=True)
+def knn_impl(request, monkeypatch):
+    """Every test in this file runs against both k-NN kernels (SLAM_KNN_IMPL is read per call)."""
+    monkeypatch.setenv("SLAM_KNN_IMPL", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("D,stride", [(61, 64), (64, 64), (32, 32), (32, 64), (17, 32)])
 @pytest.mark.parametrize("k", [1, 2])
 def test_knn_random_ragged(device, D, stride, k):
@@ -456,3 +463,17 @@ def test_score_fast_path_general_k_and_scale(device):
         rc3 = oracle.score_hypotheses(Rt[:500], k, tr, *pts, thresh, threads=8)
         c3 = _gpu_score(device, Rt[:500], k, tr, pts, thresh, want_masks=False)
         assert np.array_equal(c3.cpu().numpy()[0], rc3), thresh
+
+
+def test_knn_long_train_set_crosses_key_chunks(device):
+    # more than 8192 train rows: the matrix-core kernel scans them in chunks of 8192;
+    # duplicated rows put exact ties on both sides of the chunk boundary
+    rng = np.random.default_rng(21)
+    D = 61
+    base = _rand_desc(rng, 300, D)
+    t = np.concatenate([_rand_desc(rng, 8000, D), base[:150], base[:150], _rand_desc(rng, 700, D), base])
+    q = np.concatenate([base, _rand_desc(rng, 40, D)])
+    idx, dist, _ = gpu_match([(q, t)], D, 64, 2, device)
+    ridx, rdist = oracle_match([(q, t)], D, 2)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    assert (idx[:150, 0] == 8000 + np.arange(150)).all() and (idx[:150, 1] == 8150 + np.arange(150)).all()
