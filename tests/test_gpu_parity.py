@@ -24,8 +24,9 @@ def _rand_desc(rng, n, D):
 
 # --------------------------------------------------------------------------- knn
 @pytest.fixture(params=["mfma", "valu"], autouse=True)
-def knn_impl(request, monkeypatch):
-    """Every test in this file runs against both k-NN kernels (SLAM_KNN_IMPL is read per call)."""
+def kernel_impl(request, monkeypatch):
+    """Every test in this file runs against both implementations of the k-NN kernel (matrix-core
+    and VALU popcount); the selector is read on every call."""
     monkeypatch.setenv("SLAM_KNN_IMPL", request.param)
     return request.param
 
