@@ -28,6 +28,8 @@
 //                     never contradicts supports(): counts are bit-identical, only
 //                     ~4x cheaper (about 40 fp64 VALU ops per evaluation instead of
 //                     ~60 plus four divisions and two square roots).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace slam {
@@ -150,10 +152,25 @@ __global__ void __launch_bounds__(256) clear_mask_tail_kernel(unsigned long long
 }
 
 // ---- fast path ---------------------------------------------------------------
-// Workspace layout (doubles): [n_sets*cap][8] point records  X Y Z uL vL uR vR pad,
-// then [n_sets][2] per-set bounds kept as the bit patterns of non-negative doubles:
-// Amax = max(|X|+|Y|+|Z|) and Umax = max(|uL|+|vL|+|uR|+|vR|) over the set's points.
+// Workspace layout (in doubles, n_rec = n_sets * cap):
+//   [n_rec][8]            fp64 point records  X Y Z uL vL uR vR pad
+//   [n_rec][4]            fp32 point records (8 floats, threshold units, principal point removed)
+//                            X Y Z (uL-cx)/thr (vL-cy)/thr (uR-cx)/thr (vR-cy)/thr A2
+//                         A2 >= (|X|+|Y|+|Z|)^2, rounded up
+//   [n_sets][4]           per-set bounds kept as the bit patterns of non-negative doubles:
+//                         Amax = max(|X|+|Y|+|Z|), Umax = max(|uL|+|vL|+|uR|+|vR|),
+//                         Wmax = max(|u-cx|+|fx|, |v-cy|+|fy|)/thr over both cameras, pad
 constexpr int SCORE_REC = 8;
+constexpr int SCORE_REC32 = 8;   // floats
+constexpr int SCORE_HDR = 4;
+constexpr int SCORE_QUEUE = 16;  // undecided points a lane can park before it falls back to fp64 for all
+
+__device__ __forceinline__ double *score_recs64(const ScoreArgs &a) { return a.work; }
+__device__ __forceinline__ float *score_recs32(const ScoreArgs &a)
+{
+    return reinterpret_cast<float *>(a.work + SCORE_REC * a.n_rec);
+}
+__device__ __forceinline__ double *score_hdr(const ScoreArgs &a) { return a.work + (SCORE_REC + 4) * a.n_rec; }
 
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 {
@@ -165,116 +182,118 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return v;
 }
 
-// Widens the point data to fp64 records and reduces the two per-set magnitude bounds
-// (non-negative doubles order like their bit patterns, so an integer atomic max does it).
-// A NaN magnitude maps to the largest pattern and ends up disabling the filter for the set.
+// Widens the point data to fp64 records, writes the fp32 records and reduces the per-set
+// magnitude bounds (non-negative doubles order like their bit patterns, so an integer atomic
+// max does it).  A NaN magnitude maps to the largest pattern and ends up disabling the
+// filters for the set.
 __global__ void __launch_bounds__(256) score_prep_kernel(const ScoreArgs a, int chunks_per_set)
 {
-    __shared__ unsigned long long red[2][4];
+    __shared__ unsigned long long red[3][4];
     const int set = blockIdx.x / chunks_per_set;
     const int chunk = blockIdx.x - set * chunks_per_set;
     int n = a.n_dev ? a.n_dev[set] : a.n_host;
     n = min(max(n, 0), a.cap);
     const int i = chunk * 256 + threadIdx.x;
-    unsigned long long am = 0ull, um = 0ull;
+    unsigned long long am = 0ull, um = 0ull, wm = 0ull;
     if (i < n) {
         const size_t o = (size_t)set * a.cap + i;
         const double uL = (double)a.uL[o], vL = (double)a.vL[o], uR = (double)a.uR[o], vR = (double)a.vR[o];
         const double X = a.X[o], Y = a.Y[o], Z = a.Z[o];
-        double2 *rec = reinterpret_cast<double2 *>(a.work + SCORE_REC * o);
+        double2 *rec = reinterpret_cast<double2 *>(score_recs64(a) + SCORE_REC * o);
         rec[0] = make_double2(X, Y);
         rec[1] = make_double2(Z, uL);
         rec[2] = make_double2(vL, uR);
         rec[3] = make_double2(vR, 0.0);
         const double A = (fabs(X) + fabs(Y)) + fabs(Z);
         const double U = (fabs(uL) + fabs(vL)) + (fabs(uR) + fabs(vR));
+        const double fx = a.K.m[0], fy = a.K.m[4], cx = a.K.m[2], cy = a.K.m[5], thr = a.thresh;
+        const double ul = (uL - cx) / thr, vl = (vL - cy) / thr, ur = (uR - cx) / thr, vr = (vR - cy) / thr;
+        const double W = fmax(fmax(fabs(ul), fabs(ur)) + fabs(fx / thr), fmax(fabs(vl), fabs(vr)) + fabs(fy / thr));
+        float4 *r32 = reinterpret_cast<float4 *>(score_recs32(a) + SCORE_REC32 * o);
+        // A2 is an upper bound of A^2 after the rounding to fp32
+        r32[0] = make_float4((float)X, (float)Y, (float)Z, (float)ul);
+        r32[1] = make_float4((float)vl, (float)ur, (float)vr, (float)((A * A) * 1.000001));
         am = (A == A) ? (unsigned long long)__double_as_longlong(A) : ~0ull;
         um = (U == U) ? (unsigned long long)__double_as_longlong(U) : ~0ull;
+        wm = (W == W) ? (unsigned long long)__double_as_longlong(W) : ~0ull;
     }
     am = wave_max_u64(am);
     um = wave_max_u64(um);
+    wm = wave_max_u64(wm);
     if ((threadIdx.x & 63) == 0) {
         red[0][threadIdx.x >> 6] = am;
         red[1][threadIdx.x >> 6] = um;
+        red[2][threadIdx.x >> 6] = wm;
     }
     __syncthreads();
-    if (threadIdx.x < 2) {
+    if (threadIdx.x < 3) {
         unsigned long long m = red[threadIdx.x][0];
 #pragma unroll
         for (int w = 1; w < 4; ++w)
             m = red[threadIdx.x][w] > m ? red[threadIdx.x][w] : m;
-        unsigned long long *hdr = reinterpret_cast<unsigned long long *>(a.work + SCORE_REC * a.n_rec) + 2 * set;
+        unsigned long long *hdr = reinterpret_cast<unsigned long long *>(score_hdr(a)) + SCORE_HDR * set;
         atomicMax(hdr + threadIdx.x, m);
     }
 }
 
-// RECT: t_right[1] == t_right[2] == 0 (rectified stereo, the KITTI case): both cameras
-// share hz, hy and the threshold term, and one max() serves both verdicts.
-template <bool RECT>
-__global__ void __launch_bounds__(256) score_fast_kernel(const ScoreArgs a)
-{
-    const int set = blockIdx.x / a.blocks_per_set;
-    const int blk = blockIdx.x - set * a.blocks_per_set;
-    const int h = blk * 256 + threadIdx.x;
-    if ((blk * 256 + (int)(threadIdx.x & ~63u)) >= a.H)
-        return;  // whole wavefront past the last hypothesis
-    const bool live = h < a.H;
-    const double *src = a.Rt + ((size_t)set * a.H + (live ? h : a.H - 1)) * 12;
+// One hypothesis (one lane) of the fp64 filter: K @ Rt rows, guard-band constants, and the
+// verdict for one point record.  RECT: t_right[1] == t_right[2] == 0 (rectified stereo, the
+// KITTI case): both cameras share hz, hy and the threshold term, and one max() serves both.
+struct Lane64 {
     double rt[12];
-#pragma unroll
-    for (int c = 0; c < 12; c += 2) {
-        const double2 v = *reinterpret_cast<const double2 *>(src + c);
-        rt[c] = v.x;
-        rt[c + 1] = v.y;
-    }
-    const double fx = a.K.m[0], fy = a.K.m[4], cx = a.K.m[2], cy = a.K.m[5];
-    const double thr = a.thresh;
-    const double *hdr = a.work + SCORE_REC * a.n_rec + 2 * set;
-    const double Amax = hdr[0], Umax = hdr[1];   // NaN patterns if any point of the set was NaN
-
-    double Bh = 0.0;
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-            Bh = fmax(Bh, fabs(rt[4 * r + c]));
-    // hz is trusted only above 2^-20 * (magnitude bound of the terms it was summed from)
-    const double S = (Bh * Amax + (fmax(fmax(fabs(rt[3]), fabs(rt[7])), fabs(rt[11])) + a.trmax)) *
-                     9.5367431640625e-07;
-    // guard band: kappa = 2^-25 * mag / thresh + 2^-26, folded with the threshold into
-    //   "in"  <=>  s * kq  < hz^2      (kq  = (1+kappa)/(1-kappa) / thresh^2)
-    //   "out" <=>  s > hz^2 * kq2      (kq2 = (1+kappa)/(1-kappa) * thresh^2)
-    const double mag = fabs(fx) + fabs(fy) + fabs(cx) + fabs(cy) + Umax + fabs(thr);
-    const double kappa = 2.98023223876953125e-8 * (mag / thr) + 1.490116119384765625e-8;
-    const double kp = (1.0 + kappa) / (1.0 - kappa);
-    const double kq = kp / (thr * thr), kq2 = kp * (thr * thr);
-    // Anything that makes the filter unsafe sends every evaluation of this lane to supports():
-    // NaN/Inf in the pose (fmax drops NaNs) or the bounds, thresh <= 0 or NaN, a band that is not small.
-    bool filter_ok = (thr > 0.0) && (kappa < 0.25) && (kq > 0.0) && (kq < __builtin_inf()) && (kq2 > 0.0) &&
-                     (kq2 < __builtin_inf()) && (S < __builtin_inf());
-#pragma unroll
-    for (int c = 0; c < 12; ++c)
-        filter_ok = filter_ok && (fabs(rt[c]) < __builtin_inf());
-
-    // homogeneous pixel rows of K @ Rt for the pinhole K: hx = fx*L0 + cx*L2, hy = fy*L1 + cy*L2, hz = L2
     double px[4], py[4];
+    double cr0, cr1, cr2;
+    double S, kq, kq2, thr;
+    bool filter_ok;
+
+    __device__ __forceinline__ void setup(const ScoreArgs &a, const double *src, double Amax, double Umax)
+    {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        px[c] = __builtin_fma(fx, rt[c], cx * rt[8 + c]);
-        py[c] = __builtin_fma(fy, rt[4 + c], cy * rt[8 + c]);
+        for (int c = 0; c < 12; c += 2) {
+            const double2 v = *reinterpret_cast<const double2 *>(src + c);
+            rt[c] = v.x;
+            rt[c + 1] = v.y;
+        }
+        const double fx = a.K.m[0], fy = a.K.m[4], cx = a.K.m[2], cy = a.K.m[5];
+        thr = a.thresh;
+        double Bh = 0.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                Bh = fmax(Bh, fabs(rt[4 * r + c]));
+        // hz is trusted only above 2^-20 * (magnitude bound of the terms it was summed from)
+        S = (Bh * Amax + (fmax(fmax(fabs(rt[3]), fabs(rt[7])), fabs(rt[11])) + a.trmax)) * 9.5367431640625e-07;
+        // guard band: kappa = 2^-25 * mag / thresh + 2^-26, folded with the threshold into
+        //   "in"  <=>  s * kq  < hz^2      (kq  = (1+kappa)/(1-kappa) / thresh^2)
+        //   "out" <=>  s > hz^2 * kq2      (kq2 = (1+kappa)/(1-kappa) * thresh^2)
+        const double mag = fabs(fx) + fabs(fy) + fabs(cx) + fabs(cy) + Umax + fabs(thr);
+        const double kappa = 2.98023223876953125e-8 * (mag / thr) + 1.490116119384765625e-8;
+        const double kp = (1.0 + kappa) / (1.0 - kappa);
+        kq = kp / (thr * thr);
+        kq2 = kp * (thr * thr);
+        // Anything that makes the filter unsafe sends every evaluation of this lane to supports():
+        // NaN/Inf in the pose (fmax drops NaNs) or the bounds, thresh <= 0 or NaN, a band that is not small.
+        filter_ok = (thr > 0.0) && (kappa < 0.25) && (kq > 0.0) && (kq < __builtin_inf()) && (kq2 > 0.0) &&
+                    (kq2 < __builtin_inf()) && (S < __builtin_inf());
+#pragma unroll
+        for (int c = 0; c < 12; ++c)
+            filter_ok = filter_ok && (fabs(rt[c]) < __builtin_inf());
+        // homogeneous pixel rows of K @ Rt for the pinhole K: hx = fx*L0 + cx*L2, hy = fy*L1 + cy*L2, hz = L2
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            px[c] = __builtin_fma(fx, rt[c], cx * rt[8 + c]);
+            py[c] = __builtin_fma(fy, rt[4 + c], cy * rt[8 + c]);
+        }
+        // the right camera adds a constant to each homogeneous coordinate
+        cr0 = __builtin_fma(fx, a.tr.v[0], cx * a.tr.v[2]);
+        cr1 = __builtin_fma(fy, a.tr.v[1], cy * a.tr.v[2]);
+        cr2 = a.tr.v[2];
     }
-    // the right camera adds a constant to each homogeneous coordinate
-    const double cr0 = __builtin_fma(fx, a.tr.v[0], cx * a.tr.v[2]);
-    const double cr1 = __builtin_fma(fy, a.tr.v[1], cy * a.tr.v[2]);
-    const double cr2 = a.tr.v[2];
 
-    int n = a.n_dev ? a.n_dev[set] : a.n_host;
-    n = min(max(n, 0), a.cap);
-    n = __builtin_amdgcn_readfirstlane(n);
-    const double *__restrict__ recs = a.work + (size_t)SCORE_REC * ((size_t)set * a.cap);
-    int cnt = 0;
-
-    auto eval = [&](const double (&p)[SCORE_REC]) {
+    template <bool RECT>
+    __device__ __forceinline__ bool eval(const ScoreArgs &a, const double (&p)[SCORE_REC]) const
+    {
         const double X = p[0], Y = p[1], Z = p[2], uL = p[3], vL = p[4], uR = p[5], vR = p[6];
         // filter: fused arithmetic, no division, no square root
         const double hx = __builtin_fma(px[0], X, __builtin_fma(px[1], Y, __builtin_fma(px[2], Z, px[3])));
@@ -304,8 +323,29 @@ __global__ void __launch_bounds__(256) score_fast_kernel(const ScoreArgs a)
         bool s = sure_in;
         if (unsafe || !filter_ok || !(sure_in || sure_out))
             s = supports(rt, a.K, a.tr, X, Y, Z, uL, vL, uR, vR, thr);   // float32 -> fp64 widening is exact
-        cnt += s ? 1 : 0;
-    };
+        return s;
+    }
+};
+
+template <bool RECT>
+__global__ void __launch_bounds__(256) score_fast_kernel(const ScoreArgs a)
+{
+    const int set = blockIdx.x / a.blocks_per_set;
+    const int blk = blockIdx.x - set * a.blocks_per_set;
+    const int h = blk * 256 + threadIdx.x;
+    if ((blk * 256 + (int)(threadIdx.x & ~63u)) >= a.H)
+        return;  // whole wavefront past the last hypothesis
+    const bool live = h < a.H;
+    const double *hdr = score_hdr(a) + SCORE_HDR * set;
+    Lane64 L;
+    L.setup(a, a.Rt + ((size_t)set * a.H + (live ? h : a.H - 1)) * 12, hdr[0], hdr[1]);
+
+    int n = a.n_dev ? a.n_dev[set] : a.n_host;
+    n = min(max(n, 0), a.cap);
+    n = __builtin_amdgcn_readfirstlane(n);
+    const double *__restrict__ recs = score_recs64(a) + (size_t)SCORE_REC * ((size_t)set * a.cap);
+    int cnt = 0;
+
     auto load = [&](double (&p)[SCORE_REC], int i) {
         const double *r = recs + (size_t)SCORE_REC * min(i, n - 1);
 #pragma unroll
@@ -324,20 +364,212 @@ __global__ void __launch_bounds__(256) score_fast_kernel(const ScoreArgs a)
         for (; i + 4 <= n; i += 4) {
             load(b0, i + 2);
             load(b1, i + 3);
-            eval(a0);
-            eval(a1);
+            cnt += L.eval<RECT>(a, a0) ? 1 : 0;
+            cnt += L.eval<RECT>(a, a1) ? 1 : 0;
             load(a0, i + 4);
             load(a1, i + 5);
-            eval(b0);
-            eval(b1);
+            cnt += L.eval<RECT>(a, b0) ? 1 : 0;
+            cnt += L.eval<RECT>(a, b1) ? 1 : 0;
         }
         for (; i < n; ++i) {
-            eval(a0);
+            cnt += L.eval<RECT>(a, a0) ? 1 : 0;
 #pragma unroll
             for (int c = 0; c < SCORE_REC; ++c)
                 a0[c] = a1[c];
             load(a1, i + 2);
         }
+    }
+    if (live)
+        a.counts[(size_t)set * a.H + h] = cnt;
+}
+
+// Mixed-precision kernel for rectified stereo: lane = hypothesis, points through scalar
+// loads, and a first-level filter in fp32 (twice the fp64 VALU rate) in front of the fp64
+// filter above.  Everything is scaled to threshold units with the principal point removed:
+//     dx = uc*hz - gx,  dy = vc*hz - gy,   uc = (u-cx)/thr,  gx = (fx/thr)*L0,  hz = L2
+//     supporter  <=>  a := max over cameras of sqrt(dx^2+dy^2)  <  b := |hz|
+// which is the reference's test multiplied through by |hz|/thr.  With u = 2^-24 the fp32
+// evaluation (inputs rounded once, fma chains) obeys
+//     |a^ - a| + |b^ - b|  <=  G + 2.01u (a^ + b^),    G = u * Wb * (Brot*A + T),
+//     Wb = 8.63*Wmax + 5.2,  A = |X|+|Y|+|Z|,  Brot = max |R_ij|,  T = max |t_i| + max |t_right,i|
+// (5 roundings per term of an fma chain, sqrt(2) for the two coordinates, the slack of the
+// fp64 reference evaluation itself folded into the constants).  The lane is "sure" when
+//     |m^ - w^|  >  c1*(m^ + w^) + ca*A2 + cb
+// with m^ = max(sl, sr), w^ = hz^2, c1 = tau/2 + 4.03u, ca*A2 + cb >= G^2/tau and
+// tau = 2*u*Wb*Brot (the arithmetic-geometric-mean split of G*(a^+b^)); all four inflated by
+// 1e-3 against their own fp32 rounding.  A sure lane's verdict is the sign of m^ - w^; an
+// unsure point (about 4 in 10 000 evaluations on KITTI-like data) is parked in a per-lane
+// queue and settled by Lane64::eval after the loop.  "Sure in" is impossible when |hz| is below the rounding noise of its own
+// sum, and "sure out" there needs a projected pixel hundreds of thresholds away, so the
+// division in supports() cannot disagree.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) score_mixed_kernel(const ScoreArgs a)
+{
+    const int set = blockIdx.x / a.blocks_per_set;
+    const int blk = blockIdx.x - set * a.blocks_per_set;
+    const int h = blk * 256 + threadIdx.x;
+    if ((blk * 256 + (int)(threadIdx.x & ~63u)) >= a.H)
+        return;  // whole wavefront past the last hypothesis
+    const bool live = h < a.H;
+    const double *hdr = score_hdr(a) + SCORE_HDR * set;
+    const double Amax = hdr[0], Umax = hdr[1], Wmax = hdr[2];
+    const double *pose = a.Rt + ((size_t)set * a.H + (live ? h : a.H - 1)) * 12;
+
+    // ---- fp32 lane constants ----------------------------------------------------------
+    // The fp64 lane state is only needed to settle undecided points after the loop; it is
+    // rebuilt there so that it does not occupy registers (and cost occupancy) during the loop.
+    float qx[4], qy[4], qz[4], crx, c1, ca, cb;
+    bool f32_ok;
+    {
+        Lane64 L;
+        L.setup(a, pose, Amax, Umax);
+        const double fx = a.K.m[0], fy = a.K.m[4], cx = a.K.m[2], cy = a.K.m[5], thr = a.thresh;
+        const double sfx = fx / thr, sfy = fy / thr;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            qx[c] = (float)(sfx * L.rt[c]);
+            qy[c] = (float)(sfy * L.rt[4 + c]);
+            qz[c] = (float)L.rt[8 + c];
+        }
+        crx = (float)(sfx * a.tr.v[0]);
+        double Brot = 0.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                Brot = fmax(Brot, fabs(L.rt[4 * r + c]));
+        const double T = fmax(fmax(fabs(L.rt[3]), fabs(L.rt[7])), fabs(L.rt[11])) + a.trmax;
+        const double u24 = 5.9604644775390625e-08;
+        const double Wb = 8.63 * Wmax + 5.2;
+        const double tau = 2.0 * u24 * Wb * Brot;
+        const double c1d = (0.5 * tau + 4.03 * u24) * 1.001;
+        const double cad = (2.0 * u24 * u24 * Wb * Wb * Brot * Brot / tau) * 1.001;
+        const double cbd = (2.0 * u24 * u24 * Wb * Wb * T * T / tau) * 1.001 + 1e-30;
+        c1 = (float)c1d;
+        ca = (float)cad;
+        // The fp32 stage needs a sane camera and finite, moderate magnitudes; otherwise every
+        // point of this lane goes to the fp64 path.
+        const double mag = fabs(fx) + fabs(fy) + fabs(cx) + fabs(cy) + Umax + fabs(thr);
+        f32_ok = L.filter_ok && (mag / thr < 262144.0) && (Wmax >= 0.015625) && (Wmax < 262144.0) &&
+                 (fabs(cx) <= 64.0 * thr * Wmax) && (fabs(cy) <= 64.0 * thr * Wmax) && (Brot > 1e-30) &&
+                 (tau < 0.125) && (cbd < 1e30) && (cad < 1e30) && (cad > 1e-30) && (Amax < 1e18) && (T < 1e18);
+        cb = f32_ok ? (float)cbd : __builtin_nanf("");   // a NaN bound fails every "sure" test
+    }
+
+    int n = a.n_dev ? a.n_dev[set] : a.n_host;
+    n = min(max(n, 0), a.cap);
+    n = __builtin_amdgcn_readfirstlane(n);
+    const float *__restrict__ recs32 = score_recs32(a) + (size_t)SCORE_REC32 * ((size_t)set * a.cap);
+    const double *__restrict__ recs64 = score_recs64(a) + (size_t)SCORE_REC * ((size_t)set * a.cap);
+    int cnt = 0;
+
+    // d = m - w (sign = verdict) and whether the lane is sure of it
+    auto eval32 = [&](const float *p, float &d, bool &sure) __attribute__((always_inline)) {
+        const float X = p[0], Y = p[1], Z = p[2], ul = p[3], vl = p[4], ur = p[5], vr = p[6], A2 = p[7];
+        const float hz = __builtin_fmaf(qz[0], X, __builtin_fmaf(qz[1], Y, __builtin_fmaf(qz[2], Z, qz[3])));
+        const float gx = __builtin_fmaf(qx[0], X, __builtin_fmaf(qx[1], Y, __builtin_fmaf(qx[2], Z, qx[3])));
+        const float gy = __builtin_fmaf(qy[0], X, __builtin_fmaf(qy[1], Y, __builtin_fmaf(qy[2], Z, qy[3])));
+        const float gxr = gx + crx;
+        const float dxl = __builtin_fmaf(ul, hz, -gx);
+        const float dyl = __builtin_fmaf(vl, hz, -gy);
+        const float dxr = __builtin_fmaf(ur, hz, -gxr);
+        const float dyr = __builtin_fmaf(vr, hz, -gy);
+        const float sl = __builtin_fmaf(dxl, dxl, dyl * dyl);
+        const float sr = __builtin_fmaf(dxr, dxr, dyr * dyr);
+        const float m = fmaxf(sl, sr);   // non-finite point data never gets here (bounds poison f32_ok)
+        const float w = hz * hz;
+        d = m - w;
+        const float e = m + w;
+        const float r = __builtin_fmaf(c1, e, __builtin_fmaf(ca, A2, cb));
+        sure = fabsf(d) > r;
+    };
+    auto load = [&](float (&p)[2 * SCORE_REC32], int pair, int n_pairs) __attribute__((always_inline)) {
+        const float *r = recs32 + (size_t)(2 * SCORE_REC32) * min(pair, n_pairs - 1);
+#pragma unroll
+        for (int c = 0; c < 2 * SCORE_REC32; ++c)
+            p[c] = r[c];
+    };
+    // Verdict bits are shifted into `bits` (newest in bit 0) and counted 32 at a time.  A point
+    // the lane is not sure of contributes a 0 bit and its index goes to the lane's queue in LDS;
+    // the queues are settled in fp64 after the loop.  A lane whose queue overflows (or whose fp32
+    // stage is disabled) recounts every point in fp64 instead.
+    __shared__ unsigned queue[SCORE_QUEUE][256];
+    unsigned bits = 0;
+    int qn = 0;
+    bool full = !f32_ok;
+    const int n_pairs = n >> 1;
+    auto push = [&](int i) __attribute__((always_inline)) {
+        if (!full && qn < SCORE_QUEUE)
+            queue[qn++][threadIdx.x] = (unsigned)i;
+        else
+            full = true;
+    };
+    auto step = [&](const float (&p)[2 * SCORE_REC32], int pair) __attribute__((always_inline)) {
+        float d0, d1;
+        bool s0, s1;
+        eval32(p, d0, s0);
+        eval32(p + SCORE_REC32, d1, s1);
+        bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(d0), 31);
+        bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(d1), 31);
+        if (__builtin_expect(__ballot(!(s0 && s1)) != 0ull, 0)) {
+            if (pair < n_pairs) {   // the clamped duplicate of an odd pair count is dropped below
+                if (!s0) {
+                    bits &= ~2u;
+                    push(2 * pair);
+                }
+                if (!s1) {
+                    bits &= ~1u;
+                    push(2 * pair + 1);
+                }
+            }
+        }
+    };
+
+    // Pairs of points, two pairs per trip (ping-pong scalar prefetch: a scalar wait drains every
+    // outstanding scalar load, so the loads of the next pair are issued right after the wait for
+    // the current one), 16 pairs = 32 verdict bits per popcount.  An odd pair count runs one
+    // clamped duplicate whose two bits are dropped.
+    const int n_trips = (n_pairs + 1) & ~1;
+    if (n_pairs > 0 && __ballot(!full) != 0ull) {
+        float pa[2 * SCORE_REC32], pb[2 * SCORE_REC32];
+        load(pa, 0, n_pairs);
+        for (int g = 0; g < n_trips; g += 16) {
+            const int ge = min(g + 16, n_trips);
+            for (int j = g; j < ge; j += 2) {
+                load(pb, j + 1, n_pairs);
+                step(pa, j);
+                load(pa, j + 2, n_pairs);
+                step(pb, j + 1);
+            }
+            if (ge == n_trips && (n_pairs & 1))
+                bits &= ~3u;
+            cnt += __popc(bits);
+            bits = 0;
+        }
+    }
+    if (n & 1)
+        push(n - 1);
+    // settle the queues: lane-private point indices, fp64 filter / reference evaluation
+    asm volatile("" : "+v"(pose));   // keeps the reload below from being merged with the one above
+    Lane64 L;
+    L.setup(a, pose, Amax, Umax);
+    auto eval64 = [&](int i) __attribute__((always_inline)) -> bool {
+        double p[SCORE_REC];
+        const double *r = recs64 + (size_t)SCORE_REC * i;
+#pragma unroll
+        for (int c = 0; c < SCORE_REC; ++c)
+            p[c] = r[c];
+        return L.eval<true>(a, p);
+    };
+    for (int q = 0; __ballot(q < qn) != 0ull; ++q) {
+        if (q < qn)
+            cnt += eval64((int)queue[q][threadIdx.x]) ? 1 : 0;
+    }
+    if (__ballot(full) != 0ull) {
+        int cnt64 = 0;
+        for (int i = 0; i < n; ++i)
+            cnt64 += eval64(i) ? 1 : 0;
+        if (full)
+            cnt = cnt64;
     }
     if (live)
         a.counts[(size_t)set * a.H + h] = cnt;
@@ -407,7 +639,7 @@ extern "C" int slam_score_hypotheses(const double *Rt, int n_sets, int H, const 
         pinhole = pinhole && (t_right[i] - t_right[i] == 0.0);
     if (work && !masks && pinhole && cap > 0) {
         a.n_rec = (size_t)n_sets * cap;
-        hipError_t e = hipMemsetAsync(work + SCORE_REC * a.n_rec, 0, sizeof(double) * 2 * (size_t)n_sets, s);
+        hipError_t e = hipMemsetAsync(work + (SCORE_REC + 4) * a.n_rec, 0, sizeof(double) * SCORE_HDR * (size_t)n_sets, s);
         if (e != hipSuccess)
             return fail(SLAM_ERR_LAUNCH, "slam_score_hypotheses: %s", hipGetErrorString(e));
         const int chunks = (cap + 255) / 256;
@@ -418,10 +650,18 @@ extern "C" int slam_score_hypotheses(const double *Rt, int n_sets, int H, const 
         const long long blocks = (long long)n_sets * a.blocks_per_set;
         if (blocks > 0x7FFFFFFFLL)
             return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: grid too large");
-        if (t_right[1] == 0.0 && t_right[2] == 0.0)
-            hipLaunchKernelGGL(score_fast_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
-        else
+        // SLAM_SCORE_IMPL=f64 keeps the fp64-only filter kernel for rectified stereo (A/B timing);
+        // the counts are identical either way.
+        const char *impl = getenv("SLAM_SCORE_IMPL");
+        const bool f64_only = impl && impl[0] == 'f' && impl[1] == '6';
+        if (t_right[1] == 0.0 && t_right[2] == 0.0) {
+            if (f64_only)
+                hipLaunchKernelGGL(score_fast_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+            else
+                hipLaunchKernelGGL(score_mixed_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        } else {
             hipLaunchKernelGGL(score_fast_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        }
         return check_launch("slam_score_hypotheses(fast)");
     }
 

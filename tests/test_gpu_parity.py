@@ -26,8 +26,10 @@ def _rand_desc(rng, n, D):
 @pytest.fixture(params=["mfma", "valu"], autouse=True)
 def kernel_impl(request, monkeypatch):
     """Every test in this file runs against both implementations of the k-NN kernel (matrix-core
-    and VALU popcount); the selector is read on every call."""
+    and VALU popcount) and of the filtered scoring kernel (fp32 first level and fp64 only); the
+    selectors are read on every call."""
     monkeypatch.setenv("SLAM_KNN_IMPL", request.param)
+    monkeypatch.setenv("SLAM_SCORE_IMPL", "mixed" if request.param == "mfma" else "f64")
     return request.param
 
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Interleaved A/B timing, in one process, of the two k-NN kernels the library selects through
-SLAM_KNN_IMPL (read on every call), with the scoring kernel timed beside them."""
+"""Interleaved A/B timing, in one process, of the kernel variants the library selects through
+SLAM_KNN_IMPL (matrix-core / VALU popcount) and SLAM_SCORE_IMPL (fp32 first level / fp64 only);
+both are read on every call."""
 import ctypes
 import os
 import sys
@@ -35,10 +36,11 @@ def timed(fn, reps=3):
     return e0.elapsed_time(e1) / reps
 
 
-res = {"score": {"mfma": [], "valu": []}, "knn": {"mfma": [], "valu": []}}
+res = {"score": {"mixed": [], "f64": []}, "knn": {"mfma": [], "valu": []}}
 for rnd in range(8):
-    for impl in ("mfma", "valu"):
-        res["score"][impl].append(timed(lambda: fe.score(ws, Rt, stream)))
+    for impl, simpl in (("mfma", "mixed"), ("valu", "f64")):
+        os.environ["SLAM_SCORE_IMPL"] = simpl
+        res["score"][simpl].append(timed(lambda: fe.score(ws, Rt, stream)))
         os.environ["SLAM_KNN_IMPL"] = impl
         res["knn"][impl].append(timed(lambda: (fe.stereo_match(ws, stream), fe.temporal_match(ws, stream))))
 for kname, d in res.items():
