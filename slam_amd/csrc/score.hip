@@ -402,7 +402,7 @@ __global__ void __launch_bounds__(256) score_fast_kernel(const ScoreArgs a)
 // queue and settled by Lane64::eval after the loop.  "Sure in" is impossible when |hz| is below the rounding noise of its own
 // sum, and "sure out" there needs a projected pixel hundreds of thresholds away, so the
 // division in supports() cannot disagree.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) score_mixed_kernel(const ScoreArgs a)
+__global__ void __launch_bounds__(256) score_mixed_kernel(const ScoreArgs a)
 {
     const int set = blockIdx.x / a.blocks_per_set;
     const int blk = blockIdx.x - set * a.blocks_per_set;
@@ -549,16 +549,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     if (n & 1)
         push(n - 1);
     // settle the queues: lane-private point indices, fp64 filter / reference evaluation
-    asm volatile("" : "+v"(pose));   // keeps the reload below from being merged with the one above
-    Lane64 L;
-    L.setup(a, pose, Amax, Umax);
-    auto eval64 = [&](int i) __attribute__((always_inline)) -> bool {
-        double p[SCORE_REC];
-        const double *r = recs64 + (size_t)SCORE_REC * i;
+    // (the reference evaluation itself: only the pose has to be live here, which keeps the
+    // kernel at 8 wavefronts per SIMD without spills)
+    double rt[12];
 #pragma unroll
-        for (int c = 0; c < SCORE_REC; ++c)
-            p[c] = r[c];
-        return L.eval<true>(a, p);
+    for (int c = 0; c < 12; c += 2) {
+        const double2 v = *reinterpret_cast<const double2 *>(pose + c);
+        rt[c] = v.x;
+        rt[c + 1] = v.y;
+    }
+    auto eval64 = [&](int i) __attribute__((always_inline)) -> bool {
+        const double *r = recs64 + (size_t)SCORE_REC * i;
+        return supports(rt, a.K, a.tr, r[0], r[1], r[2], r[3], r[4], r[5], r[6], a.thresh);
     };
     for (int q = 0; __ballot(q < qn) != 0ull; ++q) {
         if (q < qn)

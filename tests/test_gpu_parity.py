@@ -468,6 +468,61 @@ def test_score_fast_path_general_k_and_scale(device):
         assert np.array_equal(c3.cpu().numpy()[0], rc3), thresh
 
 
+def _band_case(rng, n, k, tr, thresh, scale=1.0):
+    """Points observed by an identity pose with both observations displaced from the exact
+    projection by thresh*(1+delta), delta swept over +-[1e-9, 1e-2]: every scale of the guard
+    bands of the filtered kernels gets hit from both sides."""
+    X = rng.uniform(-20, 20, n) * scale
+    Y = rng.uniform(-3, 2, n) * scale
+    Z = np.exp(rng.uniform(np.log(4), np.log(120), n)) * scale
+    uL = k[0, 0] * X / Z + k[0, 2]
+    vL = k[1, 1] * Y / Z + k[1, 2]
+    uR = k[0, 0] * (X + tr[0]) / Z + k[0, 2]
+    delta = rng.choice([-1.0, 1.0], n) * 10.0 ** rng.uniform(-9, -2, n)
+    ang = rng.uniform(0, 2 * np.pi, n)
+    r = thresh * (1.0 + delta)
+    right = rng.random(n) < 0.5            # which camera carries the near-threshold residual
+    uL32 = (uL + np.where(right, 0.3, r) * np.cos(ang)).astype(np.float32)
+    vL32 = (vL + np.where(right, 0.3, r) * np.sin(ang)).astype(np.float32)
+    uR32 = (uR + np.where(right, r, 0.3) * np.cos(ang)).astype(np.float32)
+    vR32 = (vL + np.where(right, r, 0.3) * np.sin(ang)).astype(np.float32)
+    return X, Y, Z, uL32, vL32, uR32, vR32
+
+
+def test_score_guard_bands_adversarial(device):
+    k, m1, m2 = read_cameras()
+    tr = m2[:, 3]
+    rng = np.random.default_rng(77)
+    eye = np.hstack([np.eye(3), np.zeros((3, 1))])
+    for thresh, scale, n in ((2.0, 1.0, 901), (2.0, 1e3, 400), (0.7, 1e-3, 333), (5.0, 1.0, 2)):
+        pts = _band_case(rng, n, k, tr * scale, thresh, scale)
+        # tight cloud of poses around the identity (most residuals stay within the sweep), a few
+        # wild ones, and non-finite / degenerate poses that must take the exact path
+        Rt = seeded_hypotheses(eye, 300, seed=3)
+        Rt[:200] = eye + (Rt[:200] - eye) * 1e-3
+        Rt[:, :, 3] *= scale
+        Rt[0] = eye
+        Rt[290] = 0.0
+        Rt[291, 1, 2] = np.nan
+        Rt[292, 0, 3] = np.inf
+        Rt[293] *= 1e200
+        Rt[294] *= 1e-200
+        Rt[295, 2, :] = [0.0, 0.0, -1.0, 50.0 * scale]     # depths through zero inside the cloud
+        with np.errstate(all="ignore"):
+            rc = oracle.score_hypotheses(Rt, k, tr * scale, *pts, thresh, threads=8)
+        counts = _gpu_score(device, Rt, k, tr * scale, pts, thresh, want_masks=False)
+        assert np.array_equal(counts.cpu().numpy()[0], rc), (thresh, scale)
+        assert 0 < rc[0] < n or n < 8      # the sweep really straddles the threshold
+    # a principal point far outside the image switches the fp32 stage off; counts stay exact
+    k3 = k.copy()
+    k3[0, 2] = 3.0e6
+    pts = _band_case(rng, 257, k3, tr, 2.0)
+    Rt = seeded_hypotheses(eye, 70, seed=5)
+    rc = oracle.score_hypotheses(Rt, k3, tr, *pts, 2.0, threads=8)
+    counts = _gpu_score(device, Rt, k3, tr, pts, 2.0, want_masks=False)
+    assert np.array_equal(counts.cpu().numpy()[0], rc)
+
+
 def test_knn_long_train_set_crosses_key_chunks(device):
     # more than 8192 train rows: the matrix-core kernel scans them in chunks of 8192;
     # duplicated rows put exact ties on both sides of the chunk boundary
