@@ -118,8 +118,14 @@ def main():
     Rt = torch.from_numpy(Rt_host).to(dev)
     gather = sharding.TableGather(ws, world, rank) if world > 1 else None
 
+    # the step's launches are recorded once into a HIP graph and replayed (SLAM_BENCH_GRAPH=0: plain launches)
+    graph = pipeline.capture(fe, ws, Rt) if os.environ.get("SLAM_BENCH_GRAPH", "1") != "0" else None
+
     def step():
-        fe.run(ws, Rt)
+        if graph is not None:
+            graph.replay()
+        else:
+            fe.run(ws, Rt)
         if gather is not None:
             gather.run()
 
@@ -254,7 +260,8 @@ def main():
         "config": {"workload": "configs[1]: consecutive frame pairs, 4-way match + PnP-RANSAC scoring of a fixed "
                                "seeded hypothesis set", "pairs_per_gpu_per_step": P, "keypoints_per_image": N,
                    "descriptor_bytes": tb.desc_bytes, "hypotheses_per_pair": H,
-                   "mean_consensus_matches": float(n_cons.mean()), "sharding": f"frame-range x{world}"},
+                   "mean_consensus_matches": float(n_cons.mean()), "sharding": f"frame-range x{world}",
+                   "launch": "hip graph replay" if graph is not None else "plain launches"},
         "roofline": dominant,
         "stages_ms": stage_ms,
         "stage_rooflines": {"match": match_roof, "score": score_roof, "triangulate": tri_roof},

@@ -207,6 +207,22 @@ class FrontEnd:
         return ws
 
 
+def capture(fe, ws, Rt=None):
+    """Record one `fe.run(ws, Rt)` into a HIP graph (torch.cuda.CUDAGraph).  `graph.replay()`
+    re-issues every launch of the front-end with one host call; the buffers of `ws`, `ws.tb`
+    and `Rt` are baked in, so new frames are fed by writing into those tensors in place."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fe.run(ws, Rt)                      # warm-up outside the capture (lazy module loads)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fe.run(ws, Rt)
+    return graph
+
+
 def consensus_to_host(ws):
     """Copy the per-pair consensus tables back: list of dicts (rows [M,4], X [M,3], ...)."""
     c = ws.cons

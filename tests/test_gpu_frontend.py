@@ -8,10 +8,12 @@ import pytest
 
 from oracle import cpu as oracle
 from oracle import numpy_twin as twin
-from slam_amd import frontend, pnp, vo
+import torch
+
+from slam_amd import frontend, pipeline, pnp, vo
 from slam_amd.constants import CONSECUTIVE, FILTERED_MATCHES, LEFT, MATCHES, RIGHT
 from slam_amd.matcher import HipBFMatcher, Matcher, PrecomputedFeatures
-from slam_amd.synthetic import SyntheticSequence, read_cameras
+from slam_amd.synthetic import SyntheticSequence, read_cameras, seeded_hypotheses
 
 pytestmark = pytest.mark.gpu
 
@@ -203,3 +205,34 @@ def test_loop_closure_consensus_matching(device, seq):
     tiny = SyntheticSequence(12, 2)
     m2_ = Matcher(algo=PrecomputedFeatures(tiny.frames))
     assert frontend.consensus_matching_of_general_two_frames(0, 1, m2_, cameras=(k, m1, m2)) == (None,) * 6
+
+
+def test_graph_replay_matches_plain_launches(device):
+    """The whole front-end recorded into a HIP graph gives the same tables as plain launches,
+    also after the inputs were changed in place."""
+    k, m1, m2 = read_cameras()
+    seq = SyntheticSequence(600, 5, seed=11)
+    P, H = 4, 300
+    Rt_host = np.stack([seeded_hypotheses(seq.relative_pose(p, p + 1), H, seed=p) for p in range(P)])
+    fe = pipeline.FrontEnd(k, m1, m2)
+    tb = pipeline.FrameTables.from_frames(seq.frames, device)
+    ws = fe.prepare(tb, n_hyp=H)
+    Rt = torch.from_numpy(Rt_host).to(device)
+    graph = pipeline.capture(fe, ws, Rt)
+    names = ("s_idx", "s_keep", "t_idx", "t_keep", "counts", "best", "n_inl", "inl_rows", "inl_loc")
+    for trial in range(2):
+        fe.run(ws, Rt)
+        torch.cuda.synchronize()
+        plain = {n: getattr(ws, n).clone() for n in names}
+        for n in names:
+            getattr(ws, n).fill_(0)
+        graph.replay()
+        torch.cuda.synchronize()
+        n_t = int(tb.offL[-2])           # temporal outputs exist for the queries of all but the last frame
+        n_i = int(ws.n_inl.sum())        # dense inlier tables are filled up to the total count
+        for n in names:
+            lim = n_t if n.startswith("t_") else (n_i if n.startswith("inl_") else None)
+            assert torch.equal(plain[n][:lim], getattr(ws, n)[:lim]), (trial, n)
+        assert n_i > 0
+        # second trial: other hypotheses written into the same tensor
+        Rt.copy_(torch.from_numpy(np.ascontiguousarray(Rt_host[:, ::-1])).to(device))

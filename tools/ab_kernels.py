@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slam_amd import pipeline                                                     # noqa: E402
 from slam_amd.synthetic import SyntheticSequence, read_cameras, seeded_hypotheses  # noqa: E402
 
-P, N, H = 128, 2000, 10000
+P, N, H = int(os.environ.get("AB_PAIRS", "128")), 2000, int(os.environ.get("AB_HYP", "10000"))
 dev = torch.device("cuda:0")
 seq = SyntheticSequence(N, P + 1)
 Rt = torch.from_numpy(np.stack([seeded_hypotheses(seq.relative_pose(p, p + 1), H, seed=6 + p) for p in range(P)])).to(dev)
