@@ -247,6 +247,84 @@ int slam_build_inlier_tables(const int32_t *pair_dev, int n_pairs,
                              int32_t *inl_rows_dev, float *inl_loc_dev,
                              int32_t *n_inl_dev, void *stream);
 
+/* ---- batched PnP-RANSAC around slam_score_hypotheses --------------------------------
+ * ransac_for_pnp (utils/utils.py:413-464) for many point sets at once.  The reference
+ * draws with Python's global `random`, solves each 4-sample with cv2 (AP3P) and walks the
+ * iterations one by one; here all hypotheses of all sets are drawn, solved and scored in
+ * one launch each and the stopping rule is applied to the counts afterwards.  Poses from
+ * these solvers agree with cv2's to solver tolerance only; the supporter counts of any
+ * given pose are exact.
+ */
+
+/*
+ * Minimal samples: replaces `random.sample(points_to_choose_from, k=4)`
+ * (utils/utils.py:427).  For set s and hypothesis h the four distinct positions in
+ * [0, n_s) come from a splitmix64 stream keyed by (seed, s, h): draw k is a uniform rank
+ * among the n_s - k positions not drawn yet.  samples [n_sets, H, 4] int32 dev,
+ * 16-byte aligned; sets with fewer than 4 points get -1s.
+ */
+int slam_ransac_sample(uint64_t seed, int n_sets, int H, const int32_t *n_dev,
+                       int n_host, int32_t *samples_dev, void *stream);
+
+/*
+ * Pose hypotheses from minimal samples: replaces
+ * solvePnP(kp_left, candidate_4_points, K, flags=cv2.SOLVEPNP_AP3P)
+ * (utils/utils.py:428,481-497).  Three-point resection on the first three
+ * correspondences of each sample (3-D point of the previous frame, left pixel of the
+ * current frame), the fourth correspondence picks among the solutions.
+ * Rt [n_sets, H, 12] f64 dev, 16-byte aligned; a failed solve (the reference's None)
+ * is written as NaNs, which slam_score_hypotheses counts as 0 supporters.
+ * K must be a pinhole matrix [fx 0 cx; 0 fy cy; 0 0 1].
+ */
+int slam_p3p_hypotheses(const double *K_host, const double *X_dev,
+                        const double *Y_dev, const double *Z_dev,
+                        const float *uL_dev, const float *vL_dev, int cap,
+                        const int32_t *n_dev, int n_host,
+                        const int32_t *samples_dev, int n_sets, int H,
+                        double *Rt_dev, void *stream);
+
+/*
+ * The sampling loop's control flow (utils/utils.py:422-446, 475-478) replayed over the
+ * supporter counts of hypotheses 0..min(H, max_iterations)-1 taken in order:
+ * strict '>' best update, epsilon = min(epsilon, 1 - count/n), I = min(ceil(log(1-0.999)
+ * / log(1-(1-epsilon)^4)), max_iterations), stop when i >= I or epsilon == 0.
+ * best [n_sets] = index of the winner (-1: no hypothesis had a supporter),
+ * best_count, best_Rt [n_sets, 12] (NaN without winner), iters [n_sets] = iterations the
+ * loop would have run (nullable).  Sets with n < 4 get -1 / 0 iterations.
+ */
+int slam_ransac_select(const int32_t *counts_dev, const double *Rt_dev, int n_sets,
+                       int H, const int32_t *n_dev, int n_host, int cap,
+                       int max_iterations, int32_t *best_dev,
+                       int32_t *best_count_dev, double *best_Rt_dev,
+                       int32_t *iters_dev, void *stream);
+
+/*
+ * Refinement of each winner on its supporters: replaces
+ * solvePnP(kp_left, supporters, K, flags=cv2.SOLVEPNP_ITERATIVE) (utils/utils.py:450-454).
+ * Levenberg-Marquardt on the left-image reprojection error over the points whose bit is
+ * set in masks [n_sets, mask_words], started from Rt0 [n_sets, 12]; at most `iterations`
+ * steps.  Rt_out [n_sets, 12]; ok [n_sets] (nullable) is 0 where fewer than 3 supporters
+ * or a non-finite system left Rt_out = Rt0 (the reference's `refined_Rt is None` branch).
+ */
+int slam_refine_poses(const double *K_host, const double *X_dev, const double *Y_dev,
+                      const double *Z_dev, const float *uL_dev, const float *vL_dev,
+                      int cap, const int32_t *n_dev, int n_host,
+                      const uint64_t *masks_dev, int mask_words,
+                      const double *Rt0_dev, int n_sets, int iterations,
+                      double *Rt_out_dev, int32_t *ok_dev, void *stream);
+
+/*
+ * Final choice (utils/utils.py:455-463): out_Rt = refined pose when its supporter count
+ * is >= the winner's, else the winner; ratio = refined count / n (always the refined
+ * pose's, as in the reference); found = 0 (and NaNs) where the set had fewer than 4
+ * points or no hypothesis had a supporter (the reference returns None).
+ */
+int slam_ransac_adopt(int n_sets, const int32_t *n_dev, int n_host, int cap,
+                      const int32_t *best_count_dev, const int32_t *ref_count_dev,
+                      const double *best_Rt_dev, const double *ref_Rt_dev,
+                      double *out_Rt_dev, double *ratio_dev, int32_t *found_dev,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -125,3 +125,12 @@ def score_hypotheses(Rt, K, t_right, X, Y, Z, uL, vL, uR, vR, thresh, want_masks
                                       _p(uL), _p(vL), _p(uR), _p(vR), N, ctypes.c_double(thresh),
                                       _p(counts), _p(masks) if want_masks else None, int(threads))
     return (counts, masks) if want_masks else counts
+
+
+def ransac_sample(seed, n_sets, H, n):
+    """[n_sets, H, 4] int32 minimal samples of the batched RANSAC's per-hypothesis generator."""
+    n = np.ascontiguousarray(n, dtype=np.int32)
+    out = np.zeros((n_sets, H, 4), dtype=np.int32)
+    if n_sets and H:
+        lib().oracle_ransac_sample(ctypes.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), int(n_sets), int(H), _p(n), _p(out))
+    return out

@@ -343,3 +343,49 @@ void oracle_score_hypotheses(const double *Rt, int H, const double *K,
         counts[h] = cnt;
     }
 }
+
+/* ---- minimal samples for the batched RANSAC -------------------------------
+ * Stand-in for random.sample(points_to_choose_from, k=4) (utils/utils.py:427)
+ * in the batched path, where every (set, hypothesis) owns a splitmix64 stream:
+ * draw k is a uniform rank among the n - k positions not taken yet.
+ */
+static uint64_t splitmix64_next(uint64_t *s)
+{
+    *s += 0x9E3779B97F4A7C15ull;
+    uint64_t z = *s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+void oracle_ransac_sample(uint64_t seed, int n_sets, int H, const int32_t *n,
+                          int32_t *samples)
+{
+    for (int set = 0; set < n_sets; ++set) {
+        for (int h = 0; h < H; ++h) {
+            int32_t *out = samples + 4 * ((size_t)set * H + h);
+            if (n[set] < 4) {
+                out[0] = out[1] = out[2] = out[3] = -1;
+                continue;
+            }
+            uint64_t s = seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(set + 1)) ^
+                         (0x8CB92BA72F3D8DD7ull * (uint64_t)(h + 1));
+            int taken[4];
+            for (int k = 0; k < 4; ++k) {
+                uint64_t r = splitmix64_next(&s);
+                int j = (int)(((r >> 32) * (uint64_t)(n[set] - k)) >> 32);
+                /* rank among the free positions -> position */
+                for (int m = 0; m < k; ++m)
+                    if (j >= taken[m])
+                        ++j;
+                out[k] = j;
+                int pos = k;
+                while (pos > 0 && taken[pos - 1] > j) {
+                    taken[pos] = taken[pos - 1];
+                    --pos;
+                }
+                taken[pos] = j;
+            }
+        }
+    }
+}

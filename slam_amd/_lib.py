@@ -24,6 +24,11 @@ EXPORTS = (
     "slam_score_hypotheses",
     "slam_select_best",
     "slam_build_inlier_tables",
+    "slam_ransac_sample",
+    "slam_p3p_hypotheses",
+    "slam_ransac_select",
+    "slam_refine_poses",
+    "slam_ransac_adopt",
 )
 
 
@@ -74,6 +79,16 @@ def load():
     lib.slam_select_best.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
     lib.slam_build_inlier_tables.restype = ci
     lib.slam_build_inlier_tables.argtypes = [vp, ci, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.slam_ransac_sample.restype = ci
+    lib.slam_ransac_sample.argtypes = [ctypes.c_uint64, ci, ci, vp, ci, vp, vp]
+    lib.slam_p3p_hypotheses.restype = ci
+    lib.slam_p3p_hypotheses.argtypes = [vp] * 6 + [ci, vp, ci, vp, ci, ci, vp, vp]
+    lib.slam_ransac_select.restype = ci
+    lib.slam_ransac_select.argtypes = [vp, vp, ci, ci, vp, ci, ci, ci, vp, vp, vp, vp, vp]
+    lib.slam_refine_poses.restype = ci
+    lib.slam_refine_poses.argtypes = [vp] * 6 + [ci, vp, ci, vp, ci, vp, ci, ci, vp, vp, vp]
+    lib.slam_ransac_adopt.restype = ci
+    lib.slam_ransac_adopt.argtypes = [ci, vp, ci, ci] + [vp] * 8
     _lib = lib
     return lib
 

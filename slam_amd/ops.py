@@ -251,3 +251,63 @@ def score_hypotheses(Rt, K, t_right, X, Y, Z, uL, vL, uR, vR, thresh=2.0, cap=No
         _dev(work, torch.float64, "work") if (fast and work is not None) else null, _stream())
     _lib.check(st, "slam_score_hypotheses")
     return (counts, masks) if want_masks else counts
+
+
+# ---- batched PnP-RANSAC around score_hypotheses ------------------------------------
+def ransac_sample(seed, n_sets, H, n_dev, device=None):
+    """[n_sets, H, 4] int32 minimal samples (slam_ransac_sample); n_dev [n_sets] int32 on the GPU."""
+    lib = _lib.load()
+    out = torch.empty((max(n_sets, 1), max(H, 1), 4), dtype=torch.int32, device=n_dev.device if device is None else device)
+    st = lib.slam_ransac_sample(ctypes.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), n_sets, H,
+                                _dev(n_dev, torch.int32, "n_dev"), 0, ctypes.c_void_p(out.data_ptr()), _stream())
+    _lib.check(st, "slam_ransac_sample")
+    return out[:n_sets, :H]
+
+
+def p3p_hypotheses(K, X, Y, Z, uL, vL, cap, n_dev, samples):
+    """[n_sets, H, 12] float64 poses from minimal samples (slam_p3p_hypotheses); NaN = no solution."""
+    lib = _lib.load()
+    n_sets, H = samples.shape[0], samples.shape[1]
+    Kh, Kp = _host_f64(K, 9, "K")
+    out = torch.empty((max(n_sets, 1), max(H, 1), 12), dtype=torch.float64, device=samples.device)
+    st = lib.slam_p3p_hypotheses(Kp, _dev(X, torch.float64, "X"), _dev(Y, torch.float64, "Y"),
+                                 _dev(Z, torch.float64, "Z"), _dev(uL, torch.float32, "uL"),
+                                 _dev(vL, torch.float32, "vL"), int(cap), _dev(n_dev, torch.int32, "n_dev"), 0,
+                                 _dev(samples, torch.int32, "samples"), n_sets, H, ctypes.c_void_p(out.data_ptr()),
+                                 _stream())
+    _lib.check(st, "slam_p3p_hypotheses")
+    return out[:n_sets, :H]
+
+
+def ransac_select(counts, Rt, n_dev, cap, max_iterations):
+    """(best, best_count, best_Rt, iters) of the stopping rule replayed over counts [n_sets, H]."""
+    lib = _lib.load()
+    n_sets, H = counts.shape
+    dev = counts.device
+    best = torch.empty(max(n_sets, 1), dtype=torch.int32, device=dev)
+    best_count = torch.empty_like(best)
+    iters = torch.empty_like(best)
+    best_Rt = torch.empty((max(n_sets, 1), 12), dtype=torch.float64, device=dev)
+    st = lib.slam_ransac_select(_dev(counts, torch.int32, "counts"), _dev(Rt, torch.float64, "Rt"), n_sets, H,
+                                _dev(n_dev, torch.int32, "n_dev"), 0, int(cap), int(max_iterations),
+                                ctypes.c_void_p(best.data_ptr()), ctypes.c_void_p(best_count.data_ptr()),
+                                ctypes.c_void_p(best_Rt.data_ptr()), ctypes.c_void_p(iters.data_ptr()), _stream())
+    _lib.check(st, "slam_ransac_select")
+    return best[:n_sets], best_count[:n_sets], best_Rt[:n_sets], iters[:n_sets]
+
+
+def refine_poses(K, X, Y, Z, uL, vL, cap, n_dev, masks, Rt0, iterations=30):
+    """(Rt [n_sets,12], ok [n_sets]) Levenberg-Marquardt refinement on the masked points (slam_refine_poses)."""
+    lib = _lib.load()
+    n_sets = Rt0.shape[0]
+    Kh, Kp = _host_f64(K, 9, "K")
+    out = torch.empty((max(n_sets, 1), 12), dtype=torch.float64, device=Rt0.device)
+    ok = torch.zeros(max(n_sets, 1), dtype=torch.int32, device=Rt0.device)
+    st = lib.slam_refine_poses(Kp, _dev(X, torch.float64, "X"), _dev(Y, torch.float64, "Y"),
+                               _dev(Z, torch.float64, "Z"), _dev(uL, torch.float32, "uL"),
+                               _dev(vL, torch.float32, "vL"), int(cap), _dev(n_dev, torch.int32, "n_dev"), 0,
+                               _dev(masks, torch.int64, "masks"), masks.shape[-1], _dev(Rt0, torch.float64, "Rt0"),
+                               n_sets, int(iterations), ctypes.c_void_p(out.data_ptr()),
+                               ctypes.c_void_p(ok.data_ptr()), _stream())
+    _lib.check(st, "slam_refine_poses")
+    return out[:n_sets], ok[:n_sets]

@@ -12,6 +12,9 @@ the whole range:
   5. supporter counting of H pose hypotheses per pair      utils/utils.py:389-410
   6. first-best winner, its supporter mask, inlier tables    utils/utils.py:438-442,455,277-278
 
+With `FrontEnd.run_ransac` the hypotheses themselves are made on the device too (minimal
+samples, P3P, the reference's stopping rule, refinement of the winner: utils/utils.py:413-464).
+
 Nothing is copied back to the host between stages.  Buffers are allocated once per
 (frame range, H) by `FrontEnd.prepare` and reused by every `run`.
 """
@@ -169,25 +172,92 @@ class FrontEnd:
         """Winner per pair (first best), its supporter mask (one more scoring call with
         H = 1, as the reference's final find_supporters, utils/utils.py:455) and the
         order-preserving inlier tables; dense=True packs the pairs back to back."""
-        c = ws.cons
         st = self.lib.slam_select_best(_p(ws.counts), _p(Rt), ws.P, ws.H, _p(ws.best), _p(ws.best_count),
                                        _p(ws.best_Rt), stream)
         _lib.check(st, "slam_select_best")
-        st = self.lib.slam_score_hypotheses(_p(ws.best_Rt), ws.P, 1, ws.hK, ws.hT, _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL),
+        self._score_one(ws, ws.best_Rt, stream)
+        self._tables(ws, stream, dense=dense)
+
+    # -- device-side RANSAC ----------------------------------------------------
+    def prepare_ransac(self, ws):
+        """Buffers for run_ransac (hypotheses are generated on the device)."""
+        if ws.H <= 0:
+            raise ValueError("prepare(..., n_hyp=H) with H > 0 is needed for RANSAC")
+        dev = ws.tb.device
+        np_ = max(ws.P, 1)
+        ws.samples = torch.empty((np_, ws.H, 4), dtype=torch.int32, device=dev)
+        ws.Rt_gen = torch.empty((np_, ws.H, 12), dtype=torch.float64, device=dev)
+        ws.iters = torch.zeros(np_, dtype=torch.int32, device=dev)
+        ws.ref_Rt = torch.empty((np_, 12), dtype=torch.float64, device=dev)
+        ws.ref_ok = torch.zeros(np_, dtype=torch.int32, device=dev)
+        ws.pose = torch.empty((np_, 12), dtype=torch.float64, device=dev)
+        ws.ratio = torch.empty(np_, dtype=torch.float64, device=dev)
+        ws.found = torch.zeros(np_, dtype=torch.int32, device=dev)
+        return ws
+
+    def _score_one(self, ws, pose, stream):
+        """Supporter count and mask of one pose per pair (find_supporters of a single Rt)."""
+        c = ws.cons
+        st = self.lib.slam_score_hypotheses(_p(pose), ws.P, 1, ws.hK, ws.hT, _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL),
                                             _p(c.vL), _p(c.uR), _p(c.vR), ws.cap, _p(c.count), 0, self.pix_thresh,
                                             _p(ws.final_count), _p(ws.final_mask), max(ws.mask_words, 1), None,
                                             stream)
-        _lib.check(st, "slam_score_hypotheses(final)")
+        _lib.check(st, "slam_score_hypotheses(single)")
+
+    def _tables(self, ws, stream, dense=True):
+        c, tb = ws.cons, ws.tb
         if dense:
             # exclusive prefix sum of the supporter counts: device-side plumbing
             torch.cumsum(ws.final_count.view(-1), 0, dtype=torch.int32, out=ws.inl_off)
             ws.inl_off.sub_(ws.final_count.view(-1))
-        tb = ws.tb
         st = self.lib.slam_build_inlier_tables(_p(ws.pair), ws.P, _p(c.rows), _p(c.count), ws.cap, _p(ws.final_mask),
                                                max(ws.mask_words, 1), _p(tb.xL), _p(tb.yL), _p(tb.xR),
                                                _p(ws.inl_off) if dense else None, _p(ws.inl_rows), _p(ws.inl_loc),
                                                _p(ws.n_inl), stream)
         _lib.check(st, "slam_build_inlier_tables")
+
+    def ransac(self, ws, seed, stream, max_iterations=None, refine_iterations=30):
+        """PnP-RANSAC of every pair on the device (utils/utils.py:413-464): H minimal samples
+        per pair from a generator keyed by (seed, pair, hypothesis), P3P, supporter counts, the
+        stopping rule replayed over the counts, refinement of the winner on its supporters,
+        the refined pose's supporters as the inlier tables.  Results: ws.pose [P,12],
+        ws.ratio [P], ws.found [P], ws.iters [P], ws.best_count [P], the inlier tables."""
+        c = ws.cons
+        max_it = ws.H if max_iterations is None else int(max_iterations)
+        lib = self.lib
+        _lib.check(lib.slam_ransac_sample(ctypes.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), ws.P, ws.H, _p(c.count), 0,
+                                          _p(ws.samples), stream), "slam_ransac_sample")
+        _lib.check(lib.slam_p3p_hypotheses(ws.hK, _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL), _p(c.vL), ws.cap, _p(c.count), 0,
+                                           _p(ws.samples), ws.P, ws.H, _p(ws.Rt_gen), stream), "slam_p3p_hypotheses")
+        self.score(ws, ws.Rt_gen, stream)
+        _lib.check(lib.slam_ransac_select(_p(ws.counts), _p(ws.Rt_gen), ws.P, ws.H, _p(c.count), 0, ws.cap, max_it,
+                                          _p(ws.best), _p(ws.best_count), _p(ws.best_Rt), _p(ws.iters), stream),
+                   "slam_ransac_select")
+        self._score_one(ws, ws.best_Rt, stream)
+        _lib.check(lib.slam_refine_poses(ws.hK, _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL), _p(c.vL), ws.cap, _p(c.count), 0,
+                                         _p(ws.final_mask), max(ws.mask_words, 1), _p(ws.best_Rt), ws.P,
+                                         int(refine_iterations), _p(ws.ref_Rt), _p(ws.ref_ok), stream),
+                   "slam_refine_poses")
+        self._score_one(ws, ws.ref_Rt, stream)          # the mask and ratio reported are the refined pose's
+        _lib.check(lib.slam_ransac_adopt(ws.P, _p(c.count), 0, ws.cap, _p(ws.best_count), _p(ws.final_count),
+                                         _p(ws.best_Rt), _p(ws.ref_Rt), _p(ws.pose), _p(ws.ratio), _p(ws.found),
+                                         stream), "slam_ransac_adopt")
+        self._tables(ws, stream)
+
+    def run_ransac(self, ws, seed, max_iterations=None):
+        """Stages 1-4 followed by the device-side RANSAC, all on the current stream."""
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if ws.F == 0:
+            return ws
+        if not hasattr(ws, "samples"):
+            self.prepare_ransac(ws)
+        self.stereo_match(ws, stream)
+        self.triangulate(ws, stream)
+        if ws.P > 0:
+            self.temporal_match(ws, stream)
+            self.join(ws, stream)
+            self.ransac(ws, seed, stream, max_iterations=max_iterations)
+        return ws
 
     def run(self, ws, Rt=None):
         """Enqueue the whole front-end for the frame range on the current stream."""

@@ -37,14 +37,16 @@ class TableGather:
     n_cons [P_r] int32.  Works on whatever device the tensors live on.
     """
 
-    def __init__(self, ws=None, world=1, rank=0, group=None):
-        self.ws, self.world, self.rank, self.group = ws, world, rank, group
+    def __init__(self, ws=None, world=1, rank=0, group=None, pose="best_Rt"):
+        """pose: which per-pair pose of the workspace travels -- "best_Rt" (winner of a given
+        hypothesis set) or "pose" (result of the device-side RANSAC)."""
+        self.ws, self.world, self.rank, self.group, self.pose = ws, world, rank, group, pose
         self.result = None
 
     def run(self):
         ws = self.ws
         P = ws.P
-        self.result = self.gather(ws.n_inl[:P], ws.inl_rows, ws.inl_loc, ws.best_Rt[:P], ws.cons.count[:P])
+        self.result = self.gather(ws.n_inl[:P], ws.inl_rows, ws.inl_loc, getattr(ws, self.pose)[:P], ws.cons.count[:P])
         return self.result
 
     def gather(self, n_inl, rows, loc, pose, n_cons):

@@ -13,7 +13,7 @@ import torch
 
 from . import frontend, pipeline
 from .constants import PIXEL_THRESH, STEREO_ROW_THRESH, VO_MAX_ITERATIONS
-from .sharding import chain_poses
+from .sharding import TableGather, chain_poses, replay_tracks
 from .track_database import TrackDatabase
 
 
@@ -58,3 +58,24 @@ def track_camera_batched(frames, cameras=None, thresh=1, max_iterations=VO_MAX_I
         db.set_ex_camera_positions(cam)
         db.set_ex_matrices(ex)
     return cam, db
+
+
+def track_camera_device(frames, seed=6, n_hyp=VO_MAX_ITERATIONS, cameras=None, thresh=1, device=None):
+    """(camera_positions [F,3], TrackDatabase) with the whole RANSAC on the device as well:
+    per pair `n_hyp` minimal samples from a generator keyed by (seed, pair, hypothesis), P3P,
+    supporter counts, the reference's stopping rule, refinement of the winner, inlier tables
+    (pipeline.FrontEnd.run_ransac).  Only the track database is replayed on the host.  The
+    draws differ from the reference's process-global `random` stream, which chains the frames
+    one after the other; everything downstream of the draws follows utils/utils.py:413-464."""
+    k, m1, m2 = cameras if cameras is not None else frontend.read_cameras()
+    if device is None:
+        device = frontend._default_device()
+    fe = pipeline.FrontEnd(k, m1, m2, row_thresh=STEREO_ROW_THRESH, ratio_thresh=thresh, pix_thresh=PIXEL_THRESH)
+    tb = pipeline.FrameTables.from_frames(frames, device)
+    ws = fe.prepare(tb, n_hyp=n_hyp)
+    fe.run_ransac(ws, seed)
+    torch.cuda.synchronize()
+    found = ws.found.cpu().numpy()[:ws.P]
+    assert found.all(), f"RANSAC Couldn't find a transformation from frame {int(np.argmin(found))} to the next one"
+    db = replay_tracks(TableGather(ws, pose="pose").run())
+    return np.asarray(db.camera_positions), db

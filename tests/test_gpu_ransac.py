@@ -1,0 +1,220 @@
+"""GPU tests of the batched device-side PnP-RANSAC: minimal samples, P3P hypotheses, the
+stopping rule, refinement, and the whole loop on synthetic frame pairs.
+
+Sampling and the stopping rule are exact against their restatements (oracle/slam_oracle.c,
+oracle/numpy_twin.py).  The pose solvers replace cv2.solvePnP, which is not available here:
+they are checked against ground truth and against the host numpy solvers to solver tolerance
+(parity unpinned, as for the host solvers); every supporter count is exact for the pose given.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu as oracle
+from oracle import numpy_twin as twin
+from slam_amd import ops, pipeline, pnp, vo
+from slam_amd.synthetic import SyntheticSequence, read_cameras, rodrigues
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def _scene(rng, n, k, noise=0.0, pose=None):
+    """n 3-D points in front of the previous camera and their pixels in the current left camera."""
+    X = np.stack([rng.uniform(-20, 20, n), rng.uniform(-3, 2, n), np.exp(rng.uniform(np.log(4), np.log(80), n))], axis=1)
+    if pose is None:
+        R = rodrigues(np.array([0.01, -0.03, 0.005]))
+        pose = np.hstack([R, np.array([[0.05], [-0.02], [-0.8]])])
+    Y = X @ pose[:, :3].T + pose[:, 3]
+    uv = np.stack([k[0, 0] * Y[:, 0] / Y[:, 2] + k[0, 2], k[1, 1] * Y[:, 1] / Y[:, 2] + k[1, 2]], axis=1)
+    uv = (uv + rng.normal(0, noise, uv.shape)).astype(np.float32)
+    return X, uv, pose
+
+
+def test_minimal_samples_match_the_oracle(device):
+    n = np.array([4, 5, 37, 1200, 3, 0, 64], dtype=np.int32)
+    H = 513
+    for seed in (0, 6, 2**63 + 12345):
+        got = ops.ransac_sample(seed, len(n), H, _t(n, device)).cpu().numpy()
+        want = oracle.ransac_sample(seed, len(n), H, n)
+        assert np.array_equal(got, want)
+    for s, ns in enumerate(n):
+        if ns < 4:
+            assert (got[s] == -1).all()
+            continue
+        assert got[s].min() >= 0 and got[s].max() < ns
+        srt = np.sort(got[s], axis=1)
+        assert (np.diff(srt, axis=1) > 0).all()            # four distinct positions
+    # every position is drawn about equally often, in every slot
+    big = ops.ransac_sample(7, 1, 200000, _t(np.array([10], np.int32), device)).cpu().numpy()[0]
+    for slot in range(4):
+        freq = np.bincount(big[:, slot], minlength=10) / big.shape[0]
+        assert np.abs(freq - 0.1).max() < 0.004
+    assert len({tuple(r) for r in big[:2000]}) > 1500
+
+
+def test_p3p_recovers_the_pose_and_agrees_with_the_host_solver(device):
+    k, m1, m2 = read_cameras()
+    rng = np.random.default_rng(3)
+    n, H = 300, 2000
+    for noise in (0.0, 0.3):
+        X, uv, pose = _scene(rng, n, k, noise)
+        n_dev = _t(np.array([n], np.int32), device)
+        smp = ops.ransac_sample(11, 1, H, n_dev)
+        Rt = ops.p3p_hypotheses(k, _t(X[:, 0], device), _t(X[:, 1], device), _t(X[:, 2], device),
+                                _t(uv[:, 0], device), _t(uv[:, 1], device), n, n_dev, smp).cpu().numpy()[0].reshape(H, 3, 4)
+        smp = smp.cpu().numpy()[0]
+        solved = np.isfinite(Rt).all(axis=(1, 2))
+        assert solved.mean() > 0.9
+        R = Rt[solved, :, :3]
+        assert np.abs(np.einsum("hij,hkj->hik", R, R) - np.eye(3)).max() < 1e-9          # rotations
+        assert np.abs(np.linalg.det(R) - 1.0).max() < 1e-9
+        # the three defining correspondences are reproduced exactly (that is what P3P solves)
+        uv64 = uv.astype(np.float64)
+        worst = 0.0
+        for h in np.flatnonzero(solved)[:400]:
+            Y = X[smp[h, :3]] @ Rt[h, :, :3].T + Rt[h, :, 3]
+            pr = np.stack([k[0, 0] * Y[:, 0] / Y[:, 2] + k[0, 2], k[1, 1] * Y[:, 1] / Y[:, 2] + k[1, 2]], axis=1)
+            worst = max(worst, np.abs(pr - uv64[smp[h, :3]]).max())
+            assert (Y[:, 2] > 0).all()
+        assert worst < 1e-5
+        if noise == 0.0:
+            err = np.abs(Rt[solved] - pose).max(axis=(1, 2))
+            # (pixels are stored as float32: ~3e-5 px of quantisation is all the noise there is)
+            assert np.median(err) < 1e-5 and (err < 1e-3).mean() > 0.97
+        # the host solver, sample by sample: same solution branch, same pose to solver tolerance
+        agree = tried = 0
+        for h in np.flatnonzero(solved)[:300]:
+            ref = pnp.p3p_4pt(X[smp[h]], uv64[smp[h]], k)
+            if ref is None:
+                continue
+            tried += 1
+            agree += np.abs(ref - Rt[h]).max() < 1e-4
+        assert tried > 250 and agree / tried > 0.95
+
+
+def test_stopping_rule_replay_matches_the_twin(device):
+    rng = np.random.default_rng(5)
+    cases = []
+    for trial in range(60):
+        n = int(rng.integers(4, 900))
+        H = int(rng.choice([1, 7, 256, 257, 1000]))
+        top = int(rng.integers(0, n + 1))
+        c = rng.integers(0, top + 1, H)
+        if trial % 3 == 0:
+            c[rng.integers(0, H)] = n                     # a perfect hypothesis: epsilon == 0 stops the loop
+        if trial % 5 == 0:
+            c[:] = 0                                      # nothing ever supported
+        if trial % 7 == 0:
+            c[: H // 2] = 0                               # failed solves first
+        cases.append((n, H, c.astype(np.int32), int(rng.choice([H, max(1, H // 3), 1000]))))
+    cases.append((3, 50, np.full(50, 3, np.int32), 50))   # fewer than four points
+    for n, H, c, max_it in cases:
+        Rt = torch.arange(H * 12, dtype=torch.float64, device=device).reshape(1, H, 12)
+        best, bc, bRt, iters = ops.ransac_select(_t(c[None], device), Rt, _t(np.array([n], np.int32), device), n, max_it)
+        if n < 4:
+            assert int(best[0]) == -1 and int(iters[0]) == 0
+            continue
+        want_best, want_iters = twin.ransac_stop_replay(c[:min(H, max_it)], n, min(H, max_it))
+        assert (int(best[0]), int(iters[0])) == (want_best, want_iters), (n, H, max_it)
+        if want_best >= 0:
+            assert int(bc[0]) == c[want_best]
+            assert torch.equal(bRt[0], Rt[0, want_best])
+        else:
+            assert int(bc[0]) == 0 and torch.isnan(bRt[0]).all()
+
+
+def test_refinement_matches_the_host_solver(device):
+    k, m1, m2 = read_cameras()
+    rng = np.random.default_rng(8)
+    n = 500
+    X, uv, pose = _scene(rng, n, k, noise=0.3)
+    mask_bits = rng.random(n) < 0.7
+    words = (n + 63) // 64
+    mask = np.zeros(words, dtype=np.uint64)
+    for i in np.flatnonzero(mask_bits):
+        mask[i >> 6] |= np.uint64(1) << np.uint64(i & 63)
+    start = pose.copy()
+    start[:, :3] = rodrigues(np.array([0.02, 0.01, -0.015])) @ start[:, :3]
+    start[:, 3] += [0.1, -0.05, 0.2]
+    Rt, ok = ops.refine_poses(k, _t(X[:, 0], device), _t(X[:, 1], device), _t(X[:, 2], device), _t(uv[:, 0], device),
+                              _t(uv[:, 1], device), n, _t(np.array([n], np.int32), device),
+                              _t(mask.view(np.int64)[None], device), _t(start.reshape(1, 12), device))
+    assert int(ok[0]) == 1
+    got = Rt.cpu().numpy()[0].reshape(3, 4)
+    want = pnp.refine_pnp(X[mask_bits], uv[mask_bits].astype(np.float64), k, start)
+    assert np.abs(got - want).max() < 1e-7
+    assert np.abs(got - pose).max() < 5e-3                    # and both sit at the noisy optimum near the truth
+    assert np.abs(got[:, :3] @ got[:, :3].T - np.eye(3)).max() < 1e-12
+    # fewer than three supporters: the start pose comes back, ok = 0
+    few = np.zeros(words, dtype=np.uint64)
+    few[0] = np.uint64(0b101)
+    Rt, ok = ops.refine_poses(k, _t(X[:, 0], device), _t(X[:, 1], device), _t(X[:, 2], device), _t(uv[:, 0], device),
+                              _t(uv[:, 1], device), n, _t(np.array([n], np.int32), device),
+                              _t(few.view(np.int64)[None], device), _t(start.reshape(1, 12), device))
+    assert int(ok[0]) == 0 and np.array_equal(Rt.cpu().numpy()[0], start.reshape(12))
+
+
+def test_device_ransac_end_to_end(device):
+    k, m1, m2 = read_cameras()
+    seq = SyntheticSequence(1200, 5, seed=21)
+    P, H = 4, 1000
+    fe = pipeline.FrontEnd(k, m1, m2)
+    tb = pipeline.FrameTables.from_frames(seq.frames, device)
+    ws = fe.prepare(tb, n_hyp=H)
+    fe.run_ransac(ws, seed=6)
+    torch.cuda.synchronize()
+    cons = pipeline.consensus_to_host(ws)
+    counts = ws.counts.cpu().numpy()
+    samples = ws.samples.cpu().numpy()
+    Rt_gen = ws.Rt_gen.cpu().numpy()
+    n_cons = ws.cons.count.cpu().numpy()
+    assert np.array_equal(samples, oracle.ransac_sample(6, P, H, n_cons[:P]))
+    for p in range(P):
+        tab = cons[p]
+        pts = (tab["X"][:, 0].copy(), tab["X"][:, 1].copy(), tab["X"][:, 2].copy(), tab["uvL"][:, 0].copy(),
+               tab["uvL"][:, 1].copy(), tab["uvR"][:, 0].copy(), tab["uvR"][:, 1].copy())
+        with np.errstate(all="ignore"):
+            rc = oracle.score_hypotheses(Rt_gen[p], k, m2[:, 3], *pts, 2.0, threads=8)
+        assert np.array_equal(counts[p], rc)                                   # exact counts of the device's poses
+        want_best, want_iters = twin.ransac_stop_replay(rc, int(n_cons[p]), H)
+        assert (int(ws.best[p]), int(ws.iters[p])) == (want_best, want_iters)
+        assert want_iters < H                                                  # the rule stopped early on clean data
+        # reported supporters = supporters of the refined pose, exactly
+        ref = ws.ref_Rt.cpu().numpy()[p]
+        rcount, rmask = oracle.score_hypotheses(ref[None], k, m2[:, 3], *pts, 2.0, want_masks=True)
+        n_ref = int(rcount[0])
+        assert int(ws.n_inl[p]) == n_ref
+        assert float(ws.ratio[p]) == n_ref / int(n_cons[p])
+        final = ws.pose.cpu().numpy()[p]
+        assert np.array_equal(final, ref if n_ref >= rc[want_best] else Rt_gen[p, want_best])
+        assert int(ws.found[p]) == 1 and n_ref >= 0.9 * n_cons[p]
+        # and the pose is the motion that generated the data
+        gt = seq.relative_pose(p, p + 1)
+        assert np.abs(final.reshape(3, 4)[:, :3] - gt[:, :3]).max() < 2e-3
+        assert np.abs(final.reshape(3, 4)[:, 3] - gt[:, 3]).max() < 3e-2
+    # inlier tables: rows of the refined pose's supporters, in consensus order
+    off = 0
+    rows = ws.inl_rows.cpu().numpy()
+    for p in range(P):
+        ref = ws.ref_Rt.cpu().numpy()[p]
+        tab = cons[p]
+        pts = (tab["X"][:, 0].copy(), tab["X"][:, 1].copy(), tab["X"][:, 2].copy(), tab["uvL"][:, 0].copy(),
+               tab["uvL"][:, 1].copy(), tab["uvR"][:, 0].copy(), tab["uvR"][:, 1].copy())
+        _, rmask = oracle.score_hypotheses(ref[None], k, m2[:, 3], *pts, 2.0, want_masks=True)
+        bits = np.unpackbits(rmask[0].view(np.uint8), bitorder="little")[:len(tab["rows"])].astype(bool)
+        assert np.array_equal(rows[off:off + bits.sum()], tab["rows"][bits])
+        off += int(bits.sum())
+
+
+def test_visual_odometry_with_device_ransac(device):
+    seq = SyntheticSequence(1000, 12, seed=4)
+    cam, db = vo.track_camera_device(seq.frames, seed=6, n_hyp=512)
+    from slam_amd.sharding import chain_poses
+    _, gt = chain_poses(np.stack([seq.relative_pose(i, i + 1) for i in range(11)]))
+    assert cam.shape == gt.shape
+    assert np.abs(cam - gt).max() < 0.05 * max(1.0, np.abs(gt).max())
+    assert db.get_num_tracks() > 500 and db.get_num_frames() >= 11
