@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(256) score_mixed_kernel(const ScoreArgs a)
     // The fp64 lane state is only needed to settle undecided points after the loop; it is
     // rebuilt there so that it does not occupy registers (and cost occupancy) during the loop.
     float qx[4], qy[4], qz[4], crx, c1, ca, cb;
-    bool f32_ok;
+    bool f32_ok, dead;
     {
         Lane64 L;
         L.setup(a, pose, Amax, Umax);
@@ -453,6 +453,14 @@ __global__ void __launch_bounds__(256) score_mixed_kernel(const ScoreArgs a)
                  (fabs(cx) <= 64.0 * thr * Wmax) && (fabs(cy) <= 64.0 * thr * Wmax) && (Brot > 1e-30) &&
                  (tau < 0.125) && (cbd < 1e30) && (cad < 1e30) && (cad > 1e-30) && (Amax < 1e18) && (T < 1e18);
         cb = f32_ok ? (float)cbd : __builtin_nanf("");   // a NaN bound fails every "sure" test
+        // A pose with a NaN or Inf entry supports nothing: with the pinhole K the depth
+        // hz = (0*L0 + 0*L1) + L2 of supports() is then NaN or Inf, and so is every projection.
+        // (Failed minimal solves arrive as NaN poses; they must not drag their wavefront into
+        // the fp64 recount.)
+        dead = false;
+#pragma unroll
+        for (int c = 0; c < 12; ++c)
+            dead = dead || !(fabs(L.rt[c]) < __builtin_inf());
     }
 
     int n = a.n_dev ? a.n_dev[set] : a.n_host;
@@ -495,9 +503,11 @@ __global__ void __launch_bounds__(256) score_mixed_kernel(const ScoreArgs a)
     __shared__ unsigned queue[SCORE_QUEUE][256];
     unsigned bits = 0;
     int qn = 0;
-    bool full = !f32_ok;
+    bool full = !f32_ok && !dead;
     const int n_pairs = n >> 1;
     auto push = [&](int i) __attribute__((always_inline)) {
+        if (dead)
+            return;
         if (!full && qn < SCORE_QUEUE)
             queue[qn++][threadIdx.x] = (unsigned)i;
         else
@@ -573,6 +583,8 @@ __global__ void __launch_bounds__(256) score_mixed_kernel(const ScoreArgs a)
         if (full)
             cnt = cnt64;
     }
+    if (dead)
+        cnt = 0;
     if (live)
         a.counts[(size_t)set * a.H + h] = cnt;
 }
