@@ -114,20 +114,45 @@ def main():
     k, m1, m2 = read_cameras()
     fe = pipeline.FrontEnd(k, m1, m2, row_thresh=2.0, ratio_thresh=1.0, pix_thresh=2.0)
     tb = pipeline.FrameTables.from_frames(seq.frames, dev)
-    ws = fe.prepare(tb, n_hyp=H, want_masks=False)
+    cap_rows = P * int(np.diff(tb.offL).max())
+    table_pairs, table_rows = sharding.agree_table_shape(P, cap_rows, device=dev) if world > 1 else (P, cap_rows)
+    ws = fe.prepare(tb, n_hyp=H, want_masks=False, table_pairs=table_pairs, table_rows=table_rows)
     Rt = torch.from_numpy(Rt_host).to(dev)
-    gather = sharding.TableGather(ws, world, rank) if world > 1 else None
-
     # the step's launches are recorded once into a HIP graph and replayed (SLAM_BENCH_GRAPH=0: plain launches)
-    graph = pipeline.capture(fe, ws, Rt) if os.environ.get("SLAM_BENCH_GRAPH", "1") != "0" else None
+    use_graph = os.environ.get("SLAM_BENCH_GRAPH", "1") != "0"
+    graph = pipeline.capture(fe, ws, Rt) if use_graph else None
+    if world > 1:
+        # Two workspaces take turns so that the gather of step i (side stream, RCCL) overlaps the
+        # kernels of step i+1; a workspace is reused only after its gather has finished.
+        slots = [(ws, graph, sharding.TableGather(ws, world, rank))]
+        ws_b = fe.prepare(tb, n_hyp=H, want_masks=False, table_pairs=table_pairs, table_rows=table_rows)
+        slots.append((ws_b, pipeline.capture(fe, ws_b, Rt) if use_graph else None, sharding.TableGather(ws_b, world, rank)))
+        side = torch.cuda.Stream()
+        sent = [None, None]
+        step_no = [0]
 
     def step():
-        if graph is not None:
-            graph.replay()
+        if world == 1:
+            if graph is not None:
+                graph.replay()
+            else:
+                fe.run(ws, Rt)
+            return
+        b = step_no[0] & 1
+        step_no[0] += 1
+        w, g, gather = slots[b]
+        main = torch.cuda.current_stream()
+        if sent[b] is not None:
+            main.wait_event(sent[b])
+        if g is not None:
+            g.replay()
         else:
-            fe.run(ws, Rt)
-        if gather is not None:
+            fe.run(w, Rt)
+        ready = main.record_event()
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
             gather.run()
+            sent[b] = side.record_event()
 
     def fence():
         torch.cuda.synchronize()
@@ -284,7 +309,9 @@ def main():
                                "seeded hypothesis set", "pairs_per_gpu_per_step": P, "keypoints_per_image": N,
                    "descriptor_bytes": tb.desc_bytes, "hypotheses_per_pair": H,
                    "mean_consensus_matches": float(n_cons.mean()), "sharding": f"frame-range x{world}",
-                   "launch": "hip graph replay" if graph is not None else "plain launches"},
+                   "launch": "hip graph replay" if graph is not None else "plain launches",
+                   "gather": "none" if world == 1 else "one fixed-size RCCL gather of the table arena per step, "
+                                                        "overlapped with the next step's kernels"},
         "roofline": dominant,
         "stages_ms": stage_ms,
         "stage_rooflines": {"match": match_roof, "score": score_roof, "triangulate": tri_roof},

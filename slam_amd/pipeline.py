@@ -23,7 +23,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import _lib, ops
+from . import _lib, ops, sharding
 
 
 class FrameTables:
@@ -82,8 +82,10 @@ class FrontEnd:
         self.row_thresh, self.ratio_thresh, self.pix_thresh = float(row_thresh), float(ratio_thresh), float(pix_thresh)
         self.lib = _lib.load()
 
-    def prepare(self, tb, n_hyp=0, want_masks=False):
-        """Allocate outputs and index tables for the frame range held by `tb`."""
+    def prepare(self, tb, n_hyp=0, want_masks=False, table_pairs=None, table_rows=None):
+        """Allocate outputs and index tables for the frame range held by `tb`.  table_pairs /
+        table_rows: capacity of the table arena that travels in the multi-GPU gather, when the
+        ranks agreed on a common shape (sharding.agree_table_shape); default: this range's own."""
         dev = tb.device
         F = tb.n_frames
         nL = np.diff(tb.offL)
@@ -115,13 +117,18 @@ class FrontEnd:
         # winner selection + inlier tables
         np_ = max(ws.P, 1)
         ws.best, ws.best_count = i32(np_), i32(np_)
-        ws.best_Rt = f64(np_, 12)
         ws.final_count = torch.zeros((np_, 1), dtype=torch.int32, device=dev)
         ws.final_mask = torch.zeros((np_, 1, max(ws.mask_words, 1)), dtype=torch.int64, device=dev)
         ws.inl_off = i32(np_)
-        ws.inl_rows = i32(max(ws.P * ws.cap, 1), 4)
-        ws.inl_loc = torch.empty((max(ws.P * ws.cap, 1), 6), dtype=torch.float32, device=dev)
-        ws.n_inl = i32(np_)
+        # everything rank 0 needs from this range lives in one arena (sharding.TableLayout)
+        ws.layout = sharding.TableLayout(max(np_, table_pairs or 0), max(ws.P * ws.cap, 1, table_rows or 0))
+        ws.arena = torch.zeros(ws.layout.nbytes, dtype=torch.uint8, device=dev)
+        ws.table_views = ws.layout.views(ws.arena)
+        ws.best_Rt = ws.table_views["pose_a"][:np_]
+        ws.pose = ws.table_views["pose_b"][:np_]
+        ws.inl_rows = ws.table_views["rows"]
+        ws.inl_loc = ws.table_views["loc"]
+        ws.n_inl = ws.table_views["n_inl"][:np_]
         # host constants must outlive the calls
         ws.hP = self.P.ctypes.data_as(ctypes.c_void_p)
         ws.hQ = self.Q.ctypes.data_as(ctypes.c_void_p)
@@ -190,7 +197,6 @@ class FrontEnd:
         ws.iters = torch.zeros(np_, dtype=torch.int32, device=dev)
         ws.ref_Rt = torch.empty((np_, 12), dtype=torch.float64, device=dev)
         ws.ref_ok = torch.zeros(np_, dtype=torch.int32, device=dev)
-        ws.pose = torch.empty((np_, 12), dtype=torch.float64, device=dev)
         ws.ratio = torch.empty(np_, dtype=torch.float64, device=dev)
         ws.found = torch.zeros(np_, dtype=torch.int32, device=dev)
         return ws

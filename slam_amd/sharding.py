@@ -29,12 +29,61 @@ def shard_pairs(n_frames, world):
     return out
 
 
+class TableLayout:
+    """Byte layout of the per-rank table arena that travels in the gather: everything rank 0
+    needs from a shard, back to back in one buffer of a size all ranks agree on, so that the
+    exchange is ONE fixed-size collective per step without any size negotiation or host sync.
+
+        pose_a [pairs,12] f64   winner of a given hypothesis set
+        pose_b [pairs,12] f64   result of the device-side RANSAC
+        rows   [rows,4]  i32    inlier rows (prev_L, prev_R, cur_L, cur_R), dense in pair order
+        loc    [rows,6]  f32    (xl, xr, yl) of both frames per inlier row
+        n_inl  [pairs]   i32    inlier rows per pair
+        n_cons [pairs]   i32    consensus rows per pair
+    """
+    FIELDS = (("pose_a", torch.float64, 12, True), ("pose_b", torch.float64, 12, True),
+              ("rows", torch.int32, 4, False), ("loc", torch.float32, 6, False),
+              ("n_inl", torch.int32, 1, True), ("n_cons", torch.int32, 1, True))
+
+    def __init__(self, pairs, rows):
+        self.pairs, self.rows = max(int(pairs), 1), max(int(rows), 1)
+        self.offset, off = {}, 0
+        for name, dtype, width, per_pair in self.FIELDS:
+            n = (self.pairs if per_pair else self.rows) * width * torch.empty((), dtype=dtype).element_size()
+            self.offset[name] = (off, n)
+            off += (n + 15) // 16 * 16
+        self.nbytes = off
+
+    def views(self, arena):
+        """name -> typed view of a uint8 arena of this layout."""
+        out = {}
+        for name, dtype, width, per_pair in self.FIELDS:
+            off, n = self.offset[name]
+            v = arena[off:off + n].view(dtype)
+            out[name] = v.reshape(-1, width) if width > 1 else v
+        return out
+
+
+def agree_table_shape(pairs, rows, group=None, device=None):
+    """(max pairs, max row capacity) over all ranks: the common arena shape (one all_reduce,
+    done once before the workspaces are allocated)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return int(pairs), int(rows)
+    on_gpu = dist.get_backend(group) != "gloo" and device is not None
+    t = torch.tensor([int(pairs), int(rows)], dtype=torch.int64, device=device if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t[0]), int(t[1])
+
+
 class TableGather:
     """Gather per-pair inlier tables from every rank to rank 0.
 
-    Per rank: n_inl [P_r] int32 (rows per pair), rows [T_r,4] int32 and loc [T_r,6]
-    float32 dense in pair order (T_r = sum n_inl), pose [P_r,12] float64, ratio inputs
-    n_cons [P_r] int32.  Works on whatever device the tensors live on.
+    `run()` sends the workspace's table arena (see TableLayout) with one fixed-size gather and
+    no host synchronisation when every rank allocated the same arena shape
+    (pipeline.FrontEnd.prepare(table_pairs=, table_rows=) from agree_table_shape); otherwise
+    it falls back to `gather()`, which negotiates sizes and sends each table on its own.
+    Works on whatever device the tensors live on (gloo ranks sharing one GPU stage through
+    host memory: a rehearsal path).
     """
 
     def __init__(self, ws=None, world=1, rank=0, group=None, pose="best_Rt"):
@@ -42,14 +91,50 @@ class TableGather:
         hypothesis set) or "pose" (result of the device-side RANSAC)."""
         self.ws, self.world, self.rank, self.group, self.pose = ws, world, rank, group, pose
         self.result = None
+        self.fixed = False
+        if ws is not None and world > 1:
+            gloo = dist.get_backend(group) == "gloo"
+            dev = "cpu" if gloo else ws.arena.device
+            mine = torch.tensor([ws.P, ws.layout.pairs, ws.layout.rows], dtype=torch.int64, device=dev)
+            every = [torch.zeros(3, dtype=torch.int64, device=dev) for _ in range(world)]
+            dist.all_gather(every, mine, group=group)
+            every = torch.stack(every).cpu().numpy()
+            self.pairs_of = [int(v) for v in every[:, 0]]
+            self.fixed = bool((every[:, 1] == every[0, 1]).all() and (every[:, 2] == every[0, 2]).all())
+            if self.fixed and rank == 0:
+                self.recv = [torch.empty(ws.layout.nbytes, dtype=torch.uint8, device=dev) for _ in range(world)]
+
+    def _shard(self, views, P):
+        pose = views["pose_b" if self.pose == "pose" else "pose_a"]
+        return dict(n_inl=views["n_inl"][:P], n_cons=views["n_cons"][:P], pose=pose[:P], rows=views["rows"],
+                    loc=views["loc"])
 
     def run(self):
+        """Tables of every rank on rank 0 (None elsewhere): list of dicts n_inl [P_r], n_cons [P_r],
+        pose [P_r,12], rows [>=T_r,4], loc [>=T_r,6]; the first sum(n_inl) rows are valid."""
         ws = self.ws
         P = ws.P
-        self.result = self.gather(ws.n_inl[:P], ws.inl_rows, ws.inl_loc, getattr(ws, self.pose)[:P], ws.cons.count[:P])
+        ws.table_views["n_cons"][:P].copy_(ws.cons.count[:P])
+        if self.world == 1:
+            self.result = [self._shard(ws.table_views, P)]
+            return self.result
+        if not self.fixed:
+            v = ws.table_views
+            pose = v["pose_b" if self.pose == "pose" else "pose_a"]
+            self.result = self.gather(v["n_inl"][:P], v["rows"], v["loc"], pose[:P], v["n_cons"][:P])
+            return self.result
+        src = ws.arena
+        if src.is_cuda and dist.get_backend(self.group) == "gloo":
+            src = src.cpu()
+        dist.gather(src, self.recv if self.rank == 0 else None, dst=0, group=self.group)
+        if self.rank != 0:
+            self.result = None
+            return None
+        self.result = [self._shard(ws.layout.views(self.recv[r]), self.pairs_of[r]) for r in range(self.world)]
         return self.result
 
     def gather(self, n_inl, rows, loc, pose, n_cons):
+        """Variable-size gather of explicit tables (sizes are exchanged first; one host sync)."""
         world, rank = self.world, self.rank
         if world > 1 and n_inl.is_cuda and dist.get_backend(self.group) == "gloo":
             # rehearsal on a box without one GPU per rank: stage through host memory
@@ -117,8 +202,9 @@ def replay_tracks(shards, first_frame=0):
     for sh in shards:
         n_inl = sh["n_inl"].cpu().numpy()
         n_cons = sh["n_cons"].cpu().numpy()
-        rows = sh["rows"].cpu().numpy()
-        loc = sh["loc"].cpu().numpy()
+        T = int(n_inl.sum())                       # the tables may carry unused capacity behind the valid rows
+        rows = sh["rows"][:T].cpu().numpy()
+        loc = sh["loc"][:T].cpu().numpy()
         pose = sh["pose"].cpu().numpy().reshape(-1, 3, 4)
         off = 0
         for p in range(n_inl.shape[0]):

@@ -75,6 +75,78 @@ def _worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
+class _Obj:
+    pass
+
+
+def _fake_workspace(tables, pairs_cap, rows_cap):
+    """A workspace as pipeline.FrontEnd.prepare lays it out, filled from host tables."""
+    ws = _Obj()
+    ws.P = tables["n_inl"].shape[0]
+    ws.layout = sharding.TableLayout(pairs_cap, rows_cap)
+    ws.arena = torch.zeros(ws.layout.nbytes, dtype=torch.uint8)
+    ws.table_views = v = ws.layout.views(ws.arena)
+    T = tables["rows"].shape[0]
+    v["n_inl"][:ws.P] = tables["n_inl"]
+    v["rows"][:T] = tables["rows"]
+    v["loc"][:T] = tables["loc"]
+    v["pose_a"][:ws.P] = tables["pose"]
+    v["rows"][T:] = -7                      # capacity behind the valid rows must never be read
+    ws.cons = _Obj()
+    ws.cons.count = tables["n_cons"]
+    return ws
+
+
+def _arena_worker(rank, world, port, out_path, common_shape):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seq, gt = _sequence()
+        s, e = sharding.shard_pairs(N_FRAMES, world)[rank]
+        mine = shard_tables(seq.frames[s:e + 1], gt[s:e], s)
+        pairs, rows = e - s, (e - s) * N_KP
+        if common_shape:
+            pairs, rows = sharding.agree_table_shape(pairs, rows)
+        g = sharding.TableGather(_fake_workspace(mine, pairs, rows), world, rank)
+        assert g.fixed == common_shape
+        for _ in range(2):                   # the receive buffers are reused from step to step
+            shards = g.run()
+        if rank == 0:
+            sharding.replay_tracks(shards).serialize(out_path)
+        else:
+            assert shards is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fixed_arena_gather_equals_single_process(tmp_path):
+    """The one-collective arena gather (equal arena shapes on all ranks) and its fallback
+    (shapes differ: 3 ranks over 7 pairs) both reproduce the single-process track database."""
+    seq, gt = _sequence()
+    ref = sharding.replay_tracks([shard_tables(seq.frames, gt, 0)])
+    from slam_amd.track_database import TrackDatabase
+    for world, common in ((2, True), (3, True), (3, False)):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        out_path = str(tmp_path / f"db_{world}_{common}.pkl")
+        mp.spawn(_arena_worker, args=(world, port, out_path, common), nprocs=world, join=True)
+        assert TrackDatabase(out_path) == ref
+
+
+def test_table_layout_views():
+    lay = sharding.TableLayout(5, 33)
+    arena = torch.zeros(lay.nbytes, dtype=torch.uint8)
+    v = lay.views(arena)
+    assert v["pose_a"].shape == (5, 12) and v["pose_b"].shape == (5, 12) and v["rows"].shape == (33, 4)
+    assert v["loc"].shape == (33, 6) and v["n_inl"].shape == (5,) and v["n_cons"].shape == (5,)
+    for i, (name, t) in enumerate(v.items()):
+        t.fill_(i + 1)
+    for i, (name, t) in enumerate(v.items()):        # no two fields overlap
+        assert (t == i + 1).all(), name
+        assert lay.offset[name][0] % 16 == 0
+
+
 def test_two_rank_gather_and_replay_equals_single_process(tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
