@@ -82,23 +82,44 @@ class FrontEnd:
         self.row_thresh, self.ratio_thresh, self.pix_thresh = float(row_thresh), float(ratio_thresh), float(pix_thresh)
         self.lib = _lib.load()
 
-    def prepare(self, tb, n_hyp=0, want_masks=False, table_pairs=None, table_rows=None):
-        """Allocate outputs and index tables for the frame range held by `tb`.  table_pairs /
-        table_rows: capacity of the table arena that travels in the multi-GPU gather, when the
-        ranks agreed on a common shape (sharding.agree_table_shape); default: this range's own."""
+    def prepare(self, tb, n_hyp=0, want_masks=False, table_pairs=None, table_rows=None, pairs=None):
+        """Allocate outputs and index tables for the frame range held by `tb`.
+
+        pairs: [P,2] frame indices (reference, candidate) to run stages 3-6 on; default: the
+        consecutive pairs (f, f+1) of the visual-odometry loop.  Arbitrary pairs are what
+        loop closure asks for (models/LoopClosure.py:112-139: any two keyframes).
+        table_pairs / table_rows: capacity of the table arena that travels in the multi-GPU
+        gather, when the ranks agreed on a common shape (sharding.agree_table_shape);
+        default: this range's own."""
         dev = tb.device
         F = tb.n_frames
         nL = np.diff(tb.offL)
         nR = np.diff(tb.offR)
         ws = Workspace()
-        ws.tb, ws.F, ws.P, ws.H = tb, F, max(F - 1, 0), int(n_hyp)
+        if pairs is None:
+            fa = np.arange(max(F - 1, 0), dtype=np.int64)
+            fb = fa + 1
+            t_off = tb.offL[:-2] if F >= 2 else np.zeros(0, dtype=np.int64)   # one temporal row per left keypoint
+            t_rows = int(tb.offL[-1])
+        else:
+            pr = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+            if pr.size and (pr.min() < 0 or pr.max() >= F):
+                raise ValueError("pairs: frame index out of range")
+            fa, fb = pr[:, 0], pr[:, 1]
+            t_off = np.concatenate([[0], np.cumsum(nL[fa])[:-1]]).astype(np.int64) if len(fa) else np.zeros(0, np.int64)
+            t_rows = int(nL[fa].sum())
+        ws.pairs_ab = np.stack([fa, fb], axis=1)
+        ws.tb, ws.F, ws.P, ws.H = tb, F, len(fa), int(n_hyp)
         ws.max_nL, ws.max_nR = int(nL.max()) if F else 0, int(nR.max()) if F else 0
         rows = int(tb.offL[-1])
         ws.rows = rows
         ws.seg_s = ops.make_segments(tb.offL[:-1], nL, tb.offR[:-1], nR, tb.offL[:-1], dev)
-        ws.seg_t = ops.make_segments(tb.offL[:-2], nL[:-1], tb.offL[1:-1], nL[1:], tb.offL[:-2], dev)
-        pair = np.stack([tb.offL[:-2], nL[:-1], tb.offL[1:-1], nL[1:], tb.offL[:-2], tb.offR[1:-1], tb.offR[:-2],
-                         np.zeros(max(F - 1, 0), dtype=np.int64)], axis=1)
+        ws.seg_t = ops.make_segments(tb.offL[fa], nL[fa], tb.offL[fb], nL[fb], t_off, dev)
+        ws.t_off = np.asarray(t_off, dtype=np.int64)
+        pair = np.stack([tb.offL[fa], nL[fa], tb.offL[fb], nL[fb], t_off, tb.offR[fb], tb.offR[fa],
+                         np.zeros(len(fa), dtype=np.int64)], axis=1)
+        if pair.size and pair.max() > 2147483647:
+            raise ValueError("row offsets exceed int32")
         ws.pair = torch.from_numpy(pair.astype(np.int32).reshape(-1, 8)).to(dev)
         i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
         u8 = lambda *s: torch.empty(s, dtype=torch.uint8, device=dev)
@@ -106,8 +127,9 @@ class FrontEnd:
         r = max(rows, 1)
         ws.s_idx, ws.s_dist, ws.s_keep = i32(r, 2), i32(r, 2), u8(r)
         ws.X, ws.Y, ws.Z, ws.valid, ws.smap = f64(r), f64(r), f64(r), u8(r), i32(r)
-        ws.t_idx, ws.t_dist, ws.t_keep = i32(r, 2), i32(r, 2), u8(r)
-        ws.cap = ws.max_nL
+        rt = max(t_rows, 1)
+        ws.t_idx, ws.t_dist, ws.t_keep = i32(rt, 2), i32(rt, 2), u8(rt)
+        ws.cap = int(nL[fa].max()) if len(fa) else 0
         ws.cons = ops.Consensus(ws.P, ws.cap, dev)
         ws.counts = torch.zeros((max(ws.P, 1), max(ws.H, 1)), dtype=torch.int32, device=dev)
         ws.mask_words = (ws.cap + 63) // 64

@@ -79,3 +79,48 @@ def track_camera_device(frames, seed=6, n_hyp=VO_MAX_ITERATIONS, cameras=None, t
     assert found.all(), f"RANSAC Couldn't find a transformation from frame {int(np.argmin(found))} to the next one"
     db = replay_tracks(TableGather(ws, pose="pose").run())
     return np.asarray(db.camera_positions), db
+
+
+def loop_closure_pairs(n_frames, keyframe_stride=20, min_gap=30):
+    """[P,2] (reference keyframe, candidate keyframe) frame indices of an all-against-earlier
+    sweep: keyframes every `keyframe_stride` frames (models/BundleAdjustment.py:205-210), each one
+    against every earlier keyframe at least `min_gap` frames back (models/LoopClosure.py:214,234)."""
+    kf = np.arange(0, n_frames, keyframe_stride)
+    out = [(int(a), int(b)) for a in kf for b in kf if a - b >= min_gap]
+    return np.asarray(out, dtype=np.int64).reshape(-1, 2)
+
+
+def loop_closure_batched(frames, pairs, cameras=None, thresh=0.6, n_hyp=None, seed=6, device=None):
+    """Consensus matching of many keyframe pairs at once: what
+    consensus_matching_of_general_two_frames (models/LoopClosure.py:112-139) does for one pair --
+    stereo matching and triangulation of both keyframes, left-left 2-NN matching at ratio
+    `thresh`, four-image join, PnP-RANSAC with 500 iterations -- as one launch per stage over
+    all pairs, RANSAC included (pipeline.FrontEnd.run_ransac).
+
+    frames: the keyframes' features, indexed by the entries of `pairs` [P,2] = (reference,
+    candidate).  Returns a dict of host arrays per pair: valid (at least LC_MIN_CONSENSUS
+    consensus matches and a pose was found: the reference returns six Nones otherwise), pose
+    [P,3,4], inliers_ratio, n_consensus, n_filtered_matches (left-left matches that passed the
+    ratio test: the caller's >= 30 gate, models/LoopClosure.py:264-266), n_inliers, and the
+    workspace with the inlier tables (rows / (xl,xr,yl) locations of the supporters)."""
+    from .constants import LC_MAX_ITERATIONS, LC_MIN_CONSENSUS
+    k, m1, m2 = cameras if cameras is not None else frontend.read_cameras()
+    if device is None:
+        device = frontend._default_device()
+    n_hyp = LC_MAX_ITERATIONS if n_hyp is None else int(n_hyp)
+    fe = pipeline.FrontEnd(k, m1, m2, row_thresh=STEREO_ROW_THRESH, ratio_thresh=thresh, pix_thresh=PIXEL_THRESH)
+    tb = pipeline.FrameTables.from_frames(frames, device)
+    ws = fe.prepare(tb, n_hyp=n_hyp, pairs=pairs)
+    fe.run_ransac(ws, seed)
+    P = ws.P
+    # kept left-left matches per pair: segment sums of the ratio-test mask
+    csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=ws.t_keep.device), ws.t_keep.to(torch.int64).cumsum(0)])
+    lo = torch.from_numpy(ws.t_off).to(csum.device)
+    hi = lo + torch.from_numpy(np.diff(tb.offL)[ws.pairs_ab[:, 0]]).to(csum.device)
+    n_filtered = (csum[hi] - csum[lo]).cpu().numpy() if P else np.zeros(0, np.int64)
+    torch.cuda.synchronize()
+    n_cons = ws.cons.count.cpu().numpy()[:P]
+    found = ws.found.cpu().numpy()[:P].astype(bool)
+    return dict(valid=found & (n_cons >= LC_MIN_CONSENSUS), pose=ws.pose.cpu().numpy()[:P].reshape(P, 3, 4),
+                inliers_ratio=ws.ratio.cpu().numpy()[:P], n_consensus=n_cons, n_filtered_matches=n_filtered,
+                n_inliers=ws.n_inl.cpu().numpy()[:P], workspace=ws)
