@@ -95,6 +95,23 @@ int slam_hamming_knn2(const uint8_t *q_dev, const uint8_t *t_dev,
                       int32_t *out_idx_dev, int32_t *out_dist_dev, void *stream);
 
 /*
+ * Float L2 k-NN with the same segment table, modes and tie rule: replaces
+ *   cv2.BFMatcher().knnMatch(q, t, k)   -- NORM_L2 on float32 descriptors, the matcher and
+ *   descriptor (SIFT, 128 floats) the reference constructs by default, models/Matcher.py:15,
+ *   called at models/Matcher.py:127,140,199,219.
+ * q, t: float32 rows of `dim` (128 or 64) values, 16-byte aligned, rows back to back.
+ * out_dist [rows, 2] float32 = sqrtf(sum_k (q_k - t_k)^2), the sum taken in fp32 in dimension
+ * order (exact, hence identical to cv2's, for integer-valued descriptors such as SIFT's).
+ * Missing neighbours hold idx -1, dist FLT_MAX.  mode 1 compares the float32 distances as
+ * Python does: (double)d0 < thr * (double)d1.
+ */
+int slam_l2_match(const float *q_dev, const float *t_dev, const int32_t *seg_dev,
+                  int batch, int max_nq, int max_nt, int dim, int k, int mode,
+                  double thr, const float *yq_dev, const float *yt_dev,
+                  int32_t *out_idx_dev, float *out_dist_dev, uint8_t *keep_dev,
+                  void *stream);
+
+/*
  * The two match filters on their own, for callers that already hold match lists.
  * slam_ratio_filter replaces Matcher.apply_threshold / apply_thresholds
  * (models/Matcher.py:148-160,178-184): idx, dist [n,2] int32 dev as written by

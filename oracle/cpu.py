@@ -134,3 +134,17 @@ def ransac_sample(seed, n_sets, H, n):
     if n_sets and H:
         lib().oracle_ransac_sample(ctypes.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), int(n_sets), int(H), _p(n), _p(out))
     return out
+
+
+def l2_knn(q, t, k, threads=1):
+    """q [Nq, D] f32, t [Nt, D] f32 -> (idx [Nq,k] i32, dist [Nq,k] f32), cv2 NORM_L2 semantics."""
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    t = np.ascontiguousarray(t, dtype=np.float32)
+    nq = q.shape[0] if q.ndim == 2 else 0
+    nt = t.shape[0] if t.ndim == 2 else 0
+    dim = q.shape[1] if nq else (t.shape[1] if nt else 0)
+    idx = np.full((nq, k), -1, dtype=np.int32)
+    dist = np.full((nq, k), np.finfo(np.float32).max, dtype=np.float32)
+    if nq:
+        lib().oracle_l2_knn(_p(q), nq, _p(t), nt, int(dim), int(k), _p(idx), _p(dist), int(threads))
+    return idx, dist

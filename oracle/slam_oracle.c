@@ -17,6 +17,7 @@
  * IEEE rounding per operation, in the order written, and the HIP kernels are
  * compiled the same way, so inlier decisions agree bit for bit.
  */
+#include <float.h>
 #include <limits.h>
 #include <math.h>
 #include <stdint.h>
@@ -386,6 +387,56 @@ void oracle_ransac_sample(uint64_t seed, int n_sets, int H, const int32_t *n,
                 }
                 taken[pos] = j;
             }
+        }
+    }
+}
+
+/* ---- float L2 k-NN ------------------------------------------------------------
+ * cv2.BFMatcher(NORM_L2).knnMatch on float32 descriptors -- the matcher the
+ * reference builds by default (models/Matcher.py:15), same scan and tie rule as
+ * the Hamming one above.  Squared distances are summed in float32 in dimension
+ * order with one rounding per dimension (fmaf); OpenCV sums the same terms in
+ * SIMD lanes, which gives the same value whenever every partial sum is exactly
+ * representable -- always for SIFT's integer-valued descriptors.  The reported
+ * distance is sqrtf of the sum; missing neighbours hold idx -1, dist FLT_MAX.
+ */
+void oracle_l2_knn(const float *q, int nq, const float *t, int nt, int dim, int k,
+                   int32_t *out_idx, float *out_dist, int threads)
+{
+    (void)threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+#endif
+    for (int i = 0; i < nq; ++i) {
+        float bd[8];
+        int32_t bi[8];
+        const int K = k > 8 ? 8 : k;
+        for (int c = 0; c < K; ++c) {
+            bd[c] = FLT_MAX;
+            bi[c] = -1;
+        }
+        const float *qi = q + (size_t)i * dim;
+        for (int j = 0; j < nt; ++j) {
+            const float *tj = t + (size_t)j * dim;
+            float d = 0.0f;
+            for (int c = 0; c < dim; ++c) {
+                const float e = qi[c] - tj[c];
+                d = fmaf(e, e, d);
+            }
+            if (d < bd[K - 1]) {
+                int p = K - 1;
+                while (p > 0 && bd[p - 1] > d) {
+                    bd[p] = bd[p - 1];
+                    bi[p] = bi[p - 1];
+                    --p;
+                }
+                bd[p] = d;
+                bi[p] = j;
+            }
+        }
+        for (int c = 0; c < K; ++c) {
+            out_idx[(size_t)i * k + c] = bi[c];
+            out_dist[(size_t)i * k + c] = bi[c] >= 0 ? sqrtf(bd[c]) : FLT_MAX;
         }
     }
 }

@@ -16,6 +16,7 @@ EXPORTS = (
     "slam_pack_descriptors",
     "slam_hamming_match",
     "slam_hamming_knn2",
+    "slam_l2_match",
     "slam_ratio_filter",
     "slam_row_filter",
     "slam_triangulate_dlt",
@@ -63,6 +64,8 @@ def load():
     lib.slam_hamming_match.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, vp]
     lib.slam_hamming_knn2.restype = ci
     lib.slam_hamming_knn2.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp]
+    lib.slam_l2_match.restype = ci
+    lib.slam_l2_match.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, vp]
     lib.slam_ratio_filter.restype = ci
     lib.slam_ratio_filter.argtypes = [vp, vp, ci, cd, vp, vp]
     lib.slam_row_filter.restype = ci

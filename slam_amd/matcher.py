@@ -44,7 +44,13 @@ class HipBFMatcher:
         return self.device
 
     def pack(self, desc):
-        """numpy [N,D] uint8 -> (device table [N,32|64], D)."""
+        """numpy [N,D] uint8 -> (device table [N,32|64], D); float descriptors (SIFT: [N,128]
+        float32, matched with the L2 norm as cv2.BFMatcher() does) -> (device table [N,D] f32, D)."""
+        if np.asarray(desc).dtype.kind == "f":
+            desc = np.ascontiguousarray(desc, dtype=np.float32)
+            if desc.ndim != 2 or desc.shape[1] not in (64, 128):
+                raise ValueError("float descriptors must be [N, 128] or [N, 64]")
+            return torch.from_numpy(desc).to(self._dev()), desc.shape[1]
         desc = np.ascontiguousarray(desc, dtype=np.uint8)
         if desc.ndim != 2:
             raise ValueError("descriptors must be a 2-D uint8 array")
@@ -56,7 +62,8 @@ class HipBFMatcher:
         return ops.pack_descriptors(torch.from_numpy(desc).to(dev), desc.shape[1]), desc.shape[1]
 
     def knn_arrays(self, query, train, k=2, mode=0, thr=0.0, yq=None, yt=None):
-        """Array form: (idx [Nq,2] int32, dist [Nq,2] int32, keep [Nq] uint8 or None) as numpy.
+        """Array form: (idx [Nq,2] int32, dist [Nq,2] int32 (float32 for float descriptors),
+        keep [Nq] uint8 or None) as numpy.
         query/train may be numpy [N,D] or already-packed device tables (tensor, D)."""
         q, Dq = query if isinstance(query, tuple) else self.pack(query)
         t, Dt = train if isinstance(train, tuple) else self.pack(train)
@@ -64,17 +71,23 @@ class HipBFMatcher:
             raise ValueError(f"descriptor lengths differ: {Dq} vs {Dt}")
         nq, nt = q.shape[0], t.shape[0]
         if nq == 0:
-            return (np.zeros((0, 2), np.int32), np.zeros((0, 2), np.int32),
+            return (np.zeros((0, 2), np.int32), np.zeros((0, 2), np.float32 if q.dtype == torch.float32 else np.int32),
                     np.zeros(0, np.uint8) if mode else None)
         dev = self._dev()
+        if q.dtype != t.dtype:
+            raise ValueError("query and train descriptors must have the same type")
         if nt == 0:
-            t = torch.zeros((1, q.shape[1]), dtype=torch.uint8, device=dev)
+            t = torch.zeros((1, q.shape[1]), dtype=q.dtype, device=dev)
         seg = torch.tensor([[0, nq, 0, nt, 0]], dtype=torch.int32, device=dev)
         tyq = torch.from_numpy(np.ascontiguousarray(yq, dtype=np.float32)).to(dev) if yq is not None else None
         tyt = torch.from_numpy(np.ascontiguousarray(yt, dtype=np.float32)).to(dev) if yt is not None else None
         if tyt is not None and tyt.numel() == 0:
             tyt = torch.zeros(1, dtype=torch.float32, device=dev)
-        idx, dist, keep = ops.hamming_match(q, t, seg, nq, nt, Dq, k=k, mode=mode, thr=thr, yq=tyq, yt=tyt, n_rows=nq)
+        if q.dtype == torch.float32:
+            idx, dist, keep = ops.l2_match(q, t, seg, nq, nt, k=k, mode=mode, thr=thr, yq=tyq, yt=tyt, n_rows=nq)
+        else:
+            idx, dist, keep = ops.hamming_match(q, t, seg, nq, nt, Dq, k=k, mode=mode, thr=thr, yq=tyq, yt=tyt,
+                                                n_rows=nq)
         return idx.cpu().numpy(), dist.cpu().numpy(), (keep.cpu().numpy() if keep is not None else None)
 
     def knnMatch(self, queryDescriptors, trainDescriptors, k=2):

@@ -91,6 +91,37 @@ def hamming_match(q, t, seg, max_nq, max_nt, desc_bytes, k=2, mode=0, thr=0.0, y
     return idx, dist, keep
 
 
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+def l2_match(q, t, seg, max_nq, max_nt, k=2, mode=0, thr=0.0, yq=None, yt=None, n_rows=None):
+    """Batched float L2 k-NN with the fused filter (slam_l2_match).
+
+    q, t: [rows, 128|64] float32 descriptor tables.  seg: [batch,5] int32.
+    Returns (idx [n_rows,2] i32, dist [n_rows,2] f32, keep [n_rows] u8 or None).
+    """
+    lib = _lib.load()
+    if q.dim() != 2 or t.dim() != 2 or q.shape[1] != t.shape[1]:
+        raise ValueError("l2_match: q and t must be [rows, dim] with equal dim")
+    batch = seg.shape[0]
+    if n_rows is None:
+        n_rows = q.shape[0]
+    dev = q.device
+    idx = torch.full((n_rows, 2), -1, dtype=torch.int32, device=dev)
+    dist = torch.full((n_rows, 2), FLT_MAX, dtype=torch.float32, device=dev)
+    keep = torch.zeros((n_rows,), dtype=torch.uint8, device=dev) if mode else None
+    null = ctypes.c_void_p(0)
+    st = lib.slam_l2_match(
+        _dev(q, torch.float32, "q"), _dev(t, torch.float32, "t"), _dev(seg, torch.int32, "seg"), batch, int(max_nq),
+        int(max_nt), q.shape[1], int(k), int(mode), float(thr),
+        _dev(yq, torch.float32, "yq") if yq is not None else null,
+        _dev(yt, torch.float32, "yt") if yt is not None else null,
+        ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(dist.data_ptr()),
+        ctypes.c_void_p(keep.data_ptr()) if keep is not None else null, _stream())
+    _lib.check(st, "slam_l2_match")
+    return idx, dist, keep
+
+
 def hamming_knn2(q, t, seg, max_nq, max_nt, desc_bytes, k=2, n_rows=None):
     """Unfiltered batched Hamming k-NN (slam_hamming_knn2)."""
     lib = _lib.load()

@@ -29,7 +29,7 @@ from . import _lib, ops, sharding
 class FrameTables:
     """SoA keypoint / descriptor tables of F stereo frames in HBM.
 
-    descL/descR: [rows, 32|64] uint8, zero padded; xL,yL,xR,yR: [rows] float32;
+    descL/descR: [rows, 32|64] uint8, zero padded (or [rows, 128|64] float32); xL,yL,xR,yR: [rows] float32;
     offL/offR: host int64 [F+1] row offsets of each frame's left/right keypoints.
     """
 
@@ -44,13 +44,20 @@ class FrameTables:
 
     @classmethod
     def from_frames(cls, frames, device):
-        """frames: objects with kpL/kpR [N,2] float32 and descL/descR [N,D] uint8."""
+        """frames: objects with kpL/kpR [N,2] float32 and descL/descR [N,D] uint8 (binary
+        descriptors, Hamming norm) or [N,128|64] float32 (SIFT-like, L2 norm)."""
         D = frames[0].descL.shape[1]
+        is_float = frames[0].descL.dtype.kind == "f"
         stride = 32 if D <= 32 else 64
-        if D > 64:
-            raise ValueError("descriptors longer than 64 bytes are not supported")
+        if is_float and D not in (64, 128):
+            raise ValueError("float descriptors must have 128 or 64 dimensions")
+        if not is_float and D > 64:
+            raise ValueError("binary descriptors longer than 64 bytes are not supported")
 
         def table(arrs):
+            if is_float:
+                raw = np.ascontiguousarray(np.concatenate(arrs, axis=0), dtype=np.float32)
+                return torch.from_numpy(raw).to(device)
             raw = np.ascontiguousarray(np.concatenate(arrs, axis=0))
             return ops.pack_descriptors(torch.from_numpy(raw).to(device), D, stride)
 
@@ -125,10 +132,11 @@ class FrontEnd:
         u8 = lambda *s: torch.empty(s, dtype=torch.uint8, device=dev)
         f64 = lambda *s: torch.empty(s, dtype=torch.float64, device=dev)
         r = max(rows, 1)
-        ws.s_idx, ws.s_dist, ws.s_keep = i32(r, 2), i32(r, 2), u8(r)
+        dist_t = torch.float32 if tb.descL.dtype == torch.float32 else torch.int32
+        ws.s_idx, ws.s_dist, ws.s_keep = i32(r, 2), torch.empty((r, 2), dtype=dist_t, device=dev), u8(r)
         ws.X, ws.Y, ws.Z, ws.valid, ws.smap = f64(r), f64(r), f64(r), u8(r), i32(r)
         rt = max(t_rows, 1)
-        ws.t_idx, ws.t_dist, ws.t_keep = i32(rt, 2), i32(rt, 2), u8(rt)
+        ws.t_idx, ws.t_dist, ws.t_keep = i32(rt, 2), torch.empty((rt, 2), dtype=dist_t, device=dev), u8(rt)
         ws.cap = int(nL[fa].max()) if len(fa) else 0
         ws.cons = ops.Consensus(ws.P, ws.cap, dev)
         ws.counts = torch.zeros((max(ws.P, 1), max(ws.H, 1)), dtype=torch.int32, device=dev)
@@ -159,12 +167,19 @@ class FrontEnd:
         return ws
 
     # -- the five launches ---------------------------------------------------
+    def _match(self, q, t, seg, batch, max_nq, max_nt, desc_bytes, k, mode, thr, yq, yt, idx, dist, keep, stream, what):
+        if q.dtype == torch.float32:      # float descriptors: L2 norm, as cv2.BFMatcher() on SIFT
+            st = self.lib.slam_l2_match(_p(q), _p(t), _p(seg), batch, max_nq, max_nt, q.shape[1], k, mode, thr,
+                                        _p(yq), _p(yt), _p(idx), _p(dist), _p(keep), stream)
+        else:
+            st = self.lib.slam_hamming_match(_p(q), _p(t), _p(seg), batch, max_nq, max_nt, desc_bytes, q.shape[1], k,
+                                             mode, thr, _p(yq), _p(yt), _p(idx), _p(dist), _p(keep), stream)
+        _lib.check(st, what)
+
     def stereo_match(self, ws, stream):
         tb = ws.tb
-        st = self.lib.slam_hamming_match(_p(tb.descL), _p(tb.descR), _p(ws.seg_s), ws.F, ws.max_nL, ws.max_nR,
-                                         tb.desc_bytes, tb.descL.shape[1], 1, 2, self.row_thresh, _p(tb.yL),
-                                         _p(tb.yR), _p(ws.s_idx), _p(ws.s_dist), _p(ws.s_keep), stream)
-        _lib.check(st, "slam_hamming_match(stereo)")
+        return self._match(tb.descL, tb.descR, ws.seg_s, ws.F, ws.max_nL, ws.max_nR, tb.desc_bytes, 1, 2,
+                           self.row_thresh, tb.yL, tb.yR, ws.s_idx, ws.s_dist, ws.s_keep, stream, "match(stereo)")
 
     def triangulate(self, ws, stream):
         tb = ws.tb
@@ -175,10 +190,8 @@ class FrontEnd:
 
     def temporal_match(self, ws, stream):
         tb = ws.tb
-        st = self.lib.slam_hamming_match(_p(tb.descL), _p(tb.descL), _p(ws.seg_t), ws.P, ws.max_nL, ws.max_nL,
-                                         tb.desc_bytes, tb.descL.shape[1], 2, 1, self.ratio_thresh, None, None,
-                                         _p(ws.t_idx), _p(ws.t_dist), _p(ws.t_keep), stream)
-        _lib.check(st, "slam_hamming_match(temporal)")
+        return self._match(tb.descL, tb.descL, ws.seg_t, ws.P, ws.max_nL, ws.max_nL, tb.desc_bytes, 2, 1,
+                           self.ratio_thresh, None, None, ws.t_idx, ws.t_dist, ws.t_keep, stream, "match(temporal)")
 
     def join(self, ws, stream):
         tb, c = ws.tb, ws.cons
