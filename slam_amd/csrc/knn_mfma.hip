@@ -7,8 +7,15 @@
 // exactly, in the int32 accumulator.  Subtracting the train row's index j inside its chunk of
 // 1024 rows gives  -(1024 * (ham - pop(q)) + j): the larger the value, the better the match for
 // this query, ties towards the lower train index -- cv2's order -- so the running top-2 per
-// query is one v_add3_u32 + one v_max_i32 + one v_med3_i32 per result.  pop(q) is added back
-// when a chunk folds into the (distance << 22 | index) keys of the epilogue.
+// query is one v_max_i32 + one v_med3_i32 per result.  pop(q) is added back when a chunk folds
+// into the (distance << 22 | index) keys of the epilogue.
+//
+// The index term.  When the last 32-bit word of a descriptor row has two pad bytes (the
+// 61-byte AKAZE descriptor in a 64-byte row does), their k-slots carry j itself: the train side
+// stores (j & 31, j >> 5), the query side the weights (-1, -32), and the MFMA delivers
+// 1024*(pop(q)-ham) - j with no further work (EMBED).  Otherwise one v_sub per result subtracts
+// the wave-uniform part of j; the per-lane part (4 * lane half) is a constant of the lane,
+// irrelevant to its own top-2, and is added when the chunk folds.
 //
 // Bit expansion.  Which bit lands in which k-slot does not matter as long as both sides agree,
 // so a 32-bit word w becomes one 32-wide k-step with ONE v_and_b32 per four bits:
@@ -79,7 +86,9 @@ __device__ __forceinline__ i32x4 expand_query(uint32_t src)
     return v;
 }
 
-template <int KS, int QT>   // KS = k-steps of 32 bits (8 for 32-byte rows, 16 for 64-byte), QT = query tiles per wave
+// KS = k-steps of 32 bits (8 for 32-byte rows, 16 for 64-byte), QT = query tiles per wave,
+// EMBED = the row index rides in two pad k-slots (needs desc_bytes <= 4*KS - 3)
+template <int KS, int QT, bool EMBED>
 __global__ void __launch_bounds__(BLOCK, 2) hamming_mfma_kernel(const KnnArgs a)
 {
     constexpr int C = KS / 4;           // 16-byte chunks per packed row
@@ -119,6 +128,8 @@ __global__ void __launch_bounds__(BLOCK, 2) hamming_mfma_kernel(const KnnArgs a)
                 const uint32_t w = w4[e] & word_mask(ks, a.desc_bytes);
                 popq[t] += __popc(w);
                 bq[t][ks] = expand_query(half ? (w << 4) : w);
+                if (EMBED && ks == KS - 1 && half == 0)   // slots of pad bytes 1 and 2: weights -1 and -32
+                    bq[t][ks].x = (int)(((uint32_t)bq[t][ks].x & 0xFF0000FFu) | 0x00E0FF00u);
             }
         }
     }
@@ -146,10 +157,13 @@ __global__ void __launch_bounds__(BLOCK, 2) hamming_mfma_kernel(const KnnArgs a)
             v = a.t[(size_t)(ts + row) * C + spart];
         return v;
     };
-    auto expand_store = [&](uint8_t *buf, uint32_t w, int e) __attribute__((always_inline)) {
+    // `j`: index of the staged row inside its key chunk (EMBED: written into the two index slots)
+    auto expand_store = [&](uint8_t *buf, uint32_t w, int e, int j) __attribute__((always_inline)) {
         if (stager) {
             i32x4 hi, lo;
             expand_train(w & smask[e], hi, lo);
+            if (EMBED && e == 3 && spart == C - 1)
+                hi.x |= ((j & 31) << 8) | ((j >> 5) << 16);
             uint8_t *dst = buf + srow * ROW + spart * 128 + 32 * e;
             *reinterpret_cast<i32x4 *>(dst) = hi;
             *reinterpret_cast<i32x4 *>(dst + 16) = lo;
@@ -157,7 +171,6 @@ __global__ void __launch_bounds__(BLOCK, 2) hamming_mfma_kernel(const KnnArgs a)
     };
     // offset of accumulator register r's train row inside a 32-row tile, for this lane
     auto row_off = [&](int r) __attribute__((always_inline)) { return (r & 3) + 8 * (r >> 2) + 4 * half; };
-    const int nhalf4 = -4 * half;
     auto top2 = [&](int t, int v) __attribute__((always_inline)) {
         b2[t] = med3i(b1[t], b2[t], v);
         b1[t] = max(b1[t], v);
@@ -177,7 +190,7 @@ __global__ void __launch_bounds__(BLOCK, 2) hamming_mfma_kernel(const KnnArgs a)
         const uint32_t w0[4] = {r0.x, r0.y, r0.z, r0.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            expand_store(lds[0], w0[e], e);
+            expand_store(lds[0], w0[e], e, srow);
     }
     uint4 raw = n_st > 1 ? load_raw(1) : make_uint4(0, 0, 0, 0);
     __syncthreads();
@@ -186,7 +199,7 @@ __global__ void __launch_bounds__(BLOCK, 2) hamming_mfma_kernel(const KnnArgs a)
     // of the previous tile (`pend`, chunk-local first row pend_jb; all-sentinel when there is
     // none) and the expansion of two words of the next super-tile.
     auto tile_phase = [&](i32x16 (&acc)[QT], const i32x16 (&pend)[QT], const uint8_t *abase, int pend_jb,
-                          uint8_t *nbuf, uint32_t wa, int ea, uint32_t wb, int eb, bool expand)
+                          uint8_t *nbuf, uint32_t wa, int ea, uint32_t wb, int eb, bool expand, int next_j)
                           __attribute__((always_inline)) {
         const uint8_t *arow = abase + col * ROW + 16 * half;
         i32x4 af = *reinterpret_cast<const i32x4 *>(arow);
@@ -201,15 +214,15 @@ __global__ void __launch_bounds__(BLOCK, 2) hamming_mfma_kernel(const KnnArgs a)
 #pragma unroll
             for (int rr = 0; rr < RPS; ++rr) {
                 const int r = ks * RPS + rr;
-                const int sj = -pend_jb - ((r & 3) + 8 * (r >> 2));   // wave-uniform part of -j
+                const int sj = pend_jb + ((r & 3) + 8 * (r >> 2));   // wave-uniform part of j
 #pragma unroll
                 for (int t = 0; t < QT; ++t)
-                    top2(t, pend[t][r] + sj + nhalf4);
+                    top2(t, EMBED ? pend[t][r] : pend[t][r] - sj);
             }
             if (expand && ks == 1)
-                expand_store(nbuf, wa, ea);
+                expand_store(nbuf, wa, ea, next_j);
             if (expand && ks == KS / 2 + 1)
-                expand_store(nbuf, wb, eb);
+                expand_store(nbuf, wb, eb, next_j);
             af = afn;
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -221,7 +234,7 @@ __global__ void __launch_bounds__(BLOCK, 2) hamming_mfma_kernel(const KnnArgs a)
             const bool in = row0 + row_off(r) < tn;
 #pragma unroll
             for (int t = 0; t < QT; ++t)
-                top2(t, in ? acc[t][r] - (jb + row_off(r)) : SENT);
+                top2(t, in ? (EMBED ? acc[t][r] : acc[t][r] - (jb + (r & 3) + 8 * (r >> 2))) : SENT);
         }
     };
 
@@ -236,10 +249,11 @@ __global__ void __launch_bounds__(BLOCK, 2) hamming_mfma_kernel(const KnnArgs a)
         uint8_t *nbuf = lds[cur ^ 1];
 
         // accB still holds the second tile of the previous super-tile (same chunk: jb - 32)
-        tile_phase(accA, accB, lds[cur], jb - 32, nbuf, raw.x, 0, raw.y, 1, have_next);
+        const int next_j = ((row0 + TS) & (CHUNK - 1)) + srow;   // chunk-local index of the row this thread stages
+        tile_phase(accA, accB, lds[cur], jb - 32, nbuf, raw.x, 0, raw.y, 1, have_next, next_j);
         bool b_valid = false;
         if (row0 + 32 < tn) {
-            tile_phase(accB, accA, lds[cur] + 32 * ROW, jb, nbuf, raw.z, 2, raw.w, 3, have_next);
+            tile_phase(accB, accA, lds[cur] + 32 * ROW, jb, nbuf, raw.z, 2, raw.w, 3, have_next, next_j);
             b_valid = true;
         } else {
             top2_masked(accA, row0);
@@ -261,9 +275,10 @@ __global__ void __launch_bounds__(BLOCK, 2) hamming_mfma_kernel(const KnnArgs a)
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     if (is_candidate(v[e])) {
-                        const int key = -v[e];                       // 1024 * (ham - pop(q)) + j, j in [0, 1024)
+                        const int key = -v[e];                       // 1024 * (ham - pop(q)) + j', j' in [0, 1024)
                         const int ham = (key >> JBITS) + popq[t];    // arithmetic shift floors
-                        const uint32_t gk = ((uint32_t)ham << KEY_SHIFT) | (uint32_t)(chunk0 + (key & (CHUNK - 1)));
+                        const int j = (key & (CHUNK - 1)) + (EMBED ? 0 : 4 * half);
+                        const uint32_t gk = ((uint32_t)ham << KEY_SHIFT) | (uint32_t)(chunk0 + j);
                         insert_key(g1[t], g2[t], gk);
                     }
                 }
@@ -286,7 +301,7 @@ __global__ void __launch_bounds__(BLOCK, 2) hamming_mfma_kernel(const KnnArgs a)
     }
 }
 
-template <int KS, int QT>
+template <int KS, int QT, bool EMBED>
 int launch(const KnnArgs &a, int batch, int max_nq, hipStream_t s)
 {
     KnnArgs args = a;
@@ -294,7 +309,7 @@ int launch(const KnnArgs &a, int batch, int max_nq, hipStream_t s)
     const long long blocks = (long long)batch * args.tiles_per_item;
     if (blocks > 0x7FFFFFFFLL)
         return fail(SLAM_ERR_BAD_ARG, "slam_hamming_match: grid too large (%lld blocks)", blocks);
-    hipLaunchKernelGGL((hamming_mfma_kernel<KS, QT>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, args);
+    hipLaunchKernelGGL((hamming_mfma_kernel<KS, QT, EMBED>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, args);
     return check_launch("slam_hamming_match(mfma)");
 }
 
@@ -303,14 +318,16 @@ int launch(const KnnArgs &a, int batch, int max_nq, hipStream_t s)
 int launch_knn_mfma(const KnnArgs &a, int batch, int max_nq, int stride_bytes, hipStream_t s)
 {
     auto blocks = [&](int qt) { return (long long)batch * ((max_nq + 128 * qt - 1) / (128 * qt)); };
+    const bool wide = blocks(2) >= 512;
+    const bool embed = a.desc_bytes <= stride_bytes - 3;   // two pad bytes in the last word carry the row index
     if (stride_bytes == 64) {
-        if (blocks(2) >= 512)
-            return launch<16, 2>(a, batch, max_nq, s);
-        return launch<16, 1>(a, batch, max_nq, s);
+        if (embed)
+            return wide ? launch<16, 2, true>(a, batch, max_nq, s) : launch<16, 1, true>(a, batch, max_nq, s);
+        return wide ? launch<16, 2, false>(a, batch, max_nq, s) : launch<16, 1, false>(a, batch, max_nq, s);
     }
-    if (blocks(2) >= 512)
-        return launch<8, 2>(a, batch, max_nq, s);
-    return launch<8, 1>(a, batch, max_nq, s);
+    if (embed)
+        return wide ? launch<8, 2, true>(a, batch, max_nq, s) : launch<8, 1, true>(a, batch, max_nq, s);
+    return wide ? launch<8, 2, false>(a, batch, max_nq, s) : launch<8, 1, false>(a, batch, max_nq, s);
 }
 
 }  // namespace slam
