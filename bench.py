@@ -120,13 +120,24 @@ def main():
     Rt = torch.from_numpy(Rt_host).to(dev)
     # the step's launches are recorded once into a HIP graph and replayed (SLAM_BENCH_GRAPH=0: plain launches)
     use_graph = os.environ.get("SLAM_BENCH_GRAPH", "1") != "0"
-    graph = pipeline.capture(fe, ws, Rt) if use_graph else None
+    def try_capture(w):
+        if not use_graph:
+            return None
+        try:
+            return pipeline.capture(fe, w, Rt)
+        except Exception as exc:                      # fall back to plain launches, say so
+            print(f"[bench] rank {rank}: graph capture failed ({exc}); using plain launches", file=sys.stderr)
+            torch.cuda.synchronize()
+            return None
+
+    graph = try_capture(ws)
+    overlap = os.environ.get("SLAM_BENCH_OVERLAP", "1") != "0"
     if world > 1:
         # Two workspaces take turns so that the gather of step i (side stream, RCCL) overlaps the
         # kernels of step i+1; a workspace is reused only after its gather has finished.
         slots = [(ws, graph, sharding.TableGather(ws, world, rank))]
         ws_b = fe.prepare(tb, n_hyp=H, want_masks=False, table_pairs=table_pairs, table_rows=table_rows)
-        slots.append((ws_b, pipeline.capture(fe, ws_b, Rt) if use_graph else None, sharding.TableGather(ws_b, world, rank)))
+        slots.append((ws_b, try_capture(ws_b), sharding.TableGather(ws_b, world, rank)))
         side = torch.cuda.Stream()
         sent = [None, None]
         step_no = [0]
@@ -137,6 +148,14 @@ def main():
                 graph.replay()
             else:
                 fe.run(ws, Rt)
+            return
+        if not overlap:                                # gather on the launch stream, right after the kernels
+            w, g, gather = slots[0]
+            if g is not None:
+                g.replay()
+            else:
+                fe.run(w, Rt)
+            gather.run()
             return
         b = step_no[0] & 1
         step_no[0] += 1

@@ -96,8 +96,14 @@ __global__ void __launch_bounds__(BLOCK, 2) hamming_mfma_kernel(const KnnArgs a)
     constexpr int RPS = 16 / KS;        // accumulator registers handled per k-step slice
     __shared__ __attribute__((aligned(16))) uint8_t lds[2][TS * ROW];
 
-    const int item = blockIdx.x / a.tiles_per_item;
-    const int tile = blockIdx.x - item * a.tiles_per_item;
+    // Workgroups are dealt to the 8 XCDs round-robin by blockIdx; renumber them so that each XCD
+    // works through a contiguous run of (item, tile) pairs: the tiles of one item then share
+    // that XCD's L2 copy of the item's train rows instead of fetching it into every L2.
+    const int nb = gridDim.x, xq = nb >> 3, xr = nb & 7;
+    const int xcd = blockIdx.x & 7, nth = blockIdx.x >> 3;
+    const int bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + nth;
+    const int item = bid / a.tiles_per_item;
+    const int tile = bid - item * a.tiles_per_item;
     const int32_t *seg = a.seg + SLAM_SEG_STRIDE * item;
     const int qs = seg[0], qn = seg[1], ts = seg[2], tn = seg[3], os = seg[4];
     const int q0 = tile * (4 * QT * 32);

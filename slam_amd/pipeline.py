@@ -329,7 +329,9 @@ def capture(fe, ws, Rt=None):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    # thread-local capture mode: helper threads of the process (e.g. the collective library's
+    # watchdog polling its events) must not invalidate the recording
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
         fe.run(ws, Rt)
     return graph
 
