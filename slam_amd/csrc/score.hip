@@ -556,17 +556,38 @@ __global__ void __launch_bounds__(256) score_mixed_kernel(const ScoreArgs a)
             bits = 0;
         }
     }
-    if (n & 1)
+    if ((n & 1) && __ballot(!full) != 0ull) {
+        // odd point count: the last point alone through the fp32 stage
+        const float *r = recs32 + (size_t)SCORE_REC32 * (n - 1);
+        float p1[SCORE_REC32];
+#pragma unroll
+        for (int c = 0; c < SCORE_REC32; ++c)
+            p1[c] = r[c];
+        float d;
+        bool sure;
+        eval32(p1, d, sure);
+        if (sure)
+            cnt += d < 0.0f ? 1 : 0;
+        else
+            push(n - 1);
+    } else if (n & 1) {
         push(n - 1);
+    }
     // settle the queues: lane-private point indices, fp64 filter / reference evaluation
     // (the reference evaluation itself: only the pose has to be live here, which keeps the
     // kernel at 8 wavefronts per SIMD without spills)
+    // (only lanes that have something to settle read their pose again)
     double rt[12];
 #pragma unroll
-    for (int c = 0; c < 12; c += 2) {
-        const double2 v = *reinterpret_cast<const double2 *>(pose + c);
-        rt[c] = v.x;
-        rt[c + 1] = v.y;
+    for (int c = 0; c < 12; ++c)
+        rt[c] = 0.0;
+    if (qn > 0 || full) {
+#pragma unroll
+        for (int c = 0; c < 12; c += 2) {
+            const double2 v = *reinterpret_cast<const double2 *>(pose + c);
+            rt[c] = v.x;
+            rt[c + 1] = v.y;
+        }
     }
     auto eval64 = [&](int i) __attribute__((always_inline)) -> bool {
         const double *r = recs64 + (size_t)SCORE_REC * i;
