@@ -2,7 +2,7 @@
 """Benchmark of the MI355X stereo-SLAM front-end (matching + triangulation + RANSAC scoring).
 
 One "step" is one pass of the whole front-end over one batch of synthetic KITTI-shaped
-frames already resident in HBM: for P consecutive frame pairs (P+1 frames of N keypoints,
+frames already resident in HBM: for P consecutive frame pairs (P+1 frames of N keypoints, P = 511,
 61-byte descriptors), per pair
     1 stereo matching (k=1 + row filter), 1 DLT triangulation batch,
     1 temporal matching (k=2 + ratio test), 1 four-image consensus join,
@@ -43,7 +43,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=128, help="frame pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=511,
+                    help="frame pairs per GPU per step (512 frames: 4096 matcher workgroups = 8 full waves of the 512 "
+                         "resident ones; larger batches amortise launch tails, 127 / 255 / 1023 work as well)")
     ap.add_argument("--kp", type=int, default=2000, help="keypoints per image")
     ap.add_argument("--hyp", type=int, default=10000, help="pose hypotheses per pair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
