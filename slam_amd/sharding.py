@@ -9,6 +9,8 @@ The only exchange is a gather of the per-pair inlier tables and poses to rank 0
 tests), where the track database is rebuilt by replaying the pairs in frame order --
 track ids are handed out in arrival order, so that tail is sequential by construction.
 """
+import gc
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -199,6 +201,23 @@ def replay_tracks(shards, first_frame=0):
     db = TrackDatabase()
     poses = []
     frame = first_frame
+    # Millions of small tuples are created and none of them can be part of a reference cycle;
+    # the cyclic collector would rescan the growing store again and again (2-5x the run time).
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        frame = _replay_into(db, poses, shards, frame)
+    finally:
+        if gc_was_on:
+            gc.enable()
+    if poses:
+        ex, cam = chain_poses(np.stack(poses))
+        db.set_ex_matrices(ex)
+        db.set_ex_camera_positions(cam)
+    return db
+
+
+def _replay_into(db, poses, shards, frame):
     for sh in shards:
         n_inl = sh["n_inl"].cpu().numpy()
         n_cons = sh["n_cons"].cpu().numpy()
@@ -215,8 +234,4 @@ def replay_tracks(shards, first_frame=0):
             poses.append(pose[p])
             off += m
             frame += 1
-    if poses:
-        ex, cam = chain_poses(np.stack(poses))
-        db.set_ex_matrices(ex)
-        db.set_ex_camera_positions(cam)
-    return db
+    return frame

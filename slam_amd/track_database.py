@@ -83,17 +83,43 @@ class TrackDatabase:
 
     def update_tracks_from_tables(self, frameId, rows, loc):
         """rows [M,4] int (prev_left, prev_right, cur_left, cur_right); loc [M,6] float32
-        (xl, xr, yl of the earlier frame, then of the later one), in consensus order."""
+        (xl, xr, yl of the earlier frame, then of the later one), in consensus order.
+        Same state as update_tracks_from_frame row by row; the per-row bookkeeping of
+        add_to_track is done on local names, the counters once per pair."""
         self.prepare_to_next_pair(frameId)
         rows = np.asarray(rows)
-        loc = np.asarray(loc)
-        for m in range(rows.shape[0]):
-            prev_left, cur_left = int(rows[m, 0]), int(rows[m, 2])
-            l = [float(v) for v in loc[m]]
-            trackId = self.get_kp_trackId(prev_left, frameId)
+        if rows.shape[0] == 0:
+            return
+        prev_left = rows[:, 0].tolist()
+        cur_left = rows[:, 2].tolist()
+        loc = np.asarray(loc, dtype=np.float64).tolist()      # float32 -> Python floats, exactly
+        tracks = self._tracks
+        last_prev = self._last_insertions[frameId % 2]
+        last_cur = self._last_insertions[(frameId + 1) % 2]
+        in_prev = self._frame_ids[frameId]
+        in_cur = self._frame_ids[frameId + 1]
+        nxt = frameId + 1
+        max_len, min_len = self._max_length, self._min_length
+        for kp_prev, kp_cur, l in zip(prev_left, cur_left, loc):
+            trackId = last_prev.get(kp_prev)
             if trackId is None:
-                trackId = self.generate_new_track_id()
-            self.add_to_track(trackId, frameId, (l[0], l[1], l[2]), (l[3], l[4], l[5]), prev_left, cur_left)
+                trackId = self._next_free_trackId
+                self._next_free_trackId += 1
+            track = tracks.get(trackId)
+            if track is None:
+                track = tracks[trackId] = [(kp_prev, (l[0], l[1], l[2]), frameId)]
+                in_prev.add(trackId)
+                self._num_tracks += 1
+            track.append((kp_cur, (l[3], l[4], l[5]), nxt))
+            in_cur.add(trackId)
+            last_cur[kp_cur] = trackId
+            n = len(track)
+            if n > max_len:
+                max_len = n
+            if n < min_len:
+                min_len = n
+        self._max_length, self._min_length = max_len, min_len
+        self._num_frames = len(self._frame_ids)
 
     def add_inliers_ratio(self, frame_id, ratio):
         assert frame_id in self._frame_ids
