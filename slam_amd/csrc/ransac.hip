@@ -601,7 +601,7 @@ __global__ void __launch_bounds__(256) refine_kernel(const RefineArgs a)
         __syncthreads();
         for (int it = 0; it < a.iterations && state == 0; ++it) {
             if (tid == 0) {
-                double M[6][6], rhs[6], step[6];
+                double M[6][6], rhs[6], step[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
                 int k = 0;
                 for (int p = 0; p < 6; ++p)
                     for (int q = p; q < 6; ++q) {
@@ -613,8 +613,14 @@ __global__ void __launch_bounds__(256) refine_kernel(const RefineArgs a)
                     M[p][p] += lam * (M[p][p] + 1e-12);
                     rhs[p] = -g[p];
                 }
-                if (!solve6(M, rhs, step)) {
+                const bool solved = solve6(M, rhs, step);
+                const double tmax = fmax(fmax(fabs(pose[3]), fabs(pose[7])), fabs(pose[11]));
+                const double wmax = fmax(fmax(fabs(step[0]), fabs(step[1])), fabs(step[2]));
+                const double dmax = fmax(fmax(fabs(step[3]), fabs(step[4])), fabs(step[5]));
+                if (!solved) {
                     state = 2;
+                } else if (wmax + dmax / (1.0 + tmax) < 1e-11) {
+                    state = 1;   // converged: the step no longer moves the pose
                 } else {
                     double E[9];
                     exp_so3(step, E);

@@ -160,6 +160,8 @@ def refine_pnp(points_3d, points_2d, K, Rt0, iterations=30):
             step = np.linalg.solve(Hm + lam * np.diag(np.diag(Hm) + 1e-12), -g)
         except np.linalg.LinAlgError:
             return None
+        if np.abs(step[:3]).max() + np.abs(step[3:]).max() / (1.0 + np.abs(t).max()) < 1e-11:
+            break                                  # converged: the step no longer moves the pose
         dR = _exp_so3(step[:3])
         R2, t2 = dR @ R, dR @ t + step[3:]
         Y2, r2 = residual(R2, t2)
