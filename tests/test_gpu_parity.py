@@ -523,9 +523,37 @@ def test_score_guard_bands_adversarial(device):
     assert np.array_equal(counts.cpu().numpy()[0], rc)
 
 
+@pytest.mark.parametrize("D,stride", [(61, 64), (64, 64), (32, 32), (29, 32)])
+def test_knn_ties_across_tile_and_chunk_boundaries(device, D, stride):
+    """Exact duplicates of the queries planted on both sides of every internal boundary of the
+    matrix-core kernel's scan (32-row tiles, 64-row super-tiles, 1024-row key chunks), with and
+    without the row index riding in the descriptor's pad slots: equal distances must resolve to
+    the lower train index, and the runner-up must be the next copy."""
+    rng = np.random.default_rng(31 + D)
+    nt = 2300
+    t = _rand_desc(rng, nt, D)
+    q = _rand_desc(rng, 90, D)
+    spots = [(31, 32), (63, 64), (1023, 1024), (1022, 1025), (2047, 2048), (0, nt - 1), (1026, 2050), (95, 96),
+             (1055, 1056), (5, 2298)]
+    for i, (a, b) in enumerate(spots):
+        t[a] = q[i]
+        t[b] = q[i]
+    # triples: the winner and the runner-up both come before a third copy in a later chunk
+    t[700] = q[40]; t[1500] = q[40]; t[2200] = q[40]
+    # a near copy (distance 1) ahead of an exact copy behind a chunk boundary
+    near = q[41].copy(); near[0] ^= 1
+    t[1000] = near; t[1030] = q[41]
+    idx, dist, _ = gpu_match([(q, t)], D, stride, 2, device)
+    ridx, rdist = oracle_match([(q, t)], D, 2)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    for i, (a, b) in enumerate(spots):
+        assert idx[i].tolist() == [a, b] and dist[i].tolist() == [0, 0]
+    assert idx[40].tolist() == [700, 1500] and idx[41].tolist() == [1030, 1000] and dist[41].tolist() == [0, 1]
+
+
 def test_knn_long_train_set_crosses_key_chunks(device):
-    # more than 8192 train rows: the matrix-core kernel scans them in chunks of 8192;
-    # duplicated rows put exact ties on both sides of the chunk boundary
+    # more than 8192 train rows: the matrix-core kernel scans them chunk by chunk;
+    # duplicated rows put exact ties on both sides of chunk boundaries
     rng = np.random.default_rng(21)
     D = 61
     base = _rand_desc(rng, 300, D)
