@@ -98,7 +98,6 @@ __global__ void __launch_bounds__(BLOCK) hamming_knn_kernel(const KnnArgs a)
         const int base = tt * TT + wave * WAVE;
         const int cnt = min(WAVE, tn - base);
         const uint4 *rows = buf + wave * WAVE * C;
-#pragma unroll 2
         for (int jj = 0; jj < cnt; ++jj) {
             uint32_t tw[W];
 #pragma unroll
