@@ -231,6 +231,25 @@ int slam_score_hypotheses(const double *Rt_dev, int n_sets, int H,
                           void *stream);
 
 /*
+ * The same for hypotheses [h_begin, h_begin + H) of each set only (Rt, counts and masks keep
+ * their row stride of H_total hypotheses per set), leaving alone every set whose entry in
+ * skip_dev [n_sets] (nullable) is non-zero.  This is how the batched RANSAC scores a first
+ * slice of the hypotheses, lets the stopping rule decide which sets are finished, and scores
+ * the rest only for the others -- the reference never scores a hypothesis after its loop has
+ * stopped either (utils/utils.py:425).  Masks need the full range and no skip list.
+ */
+int slam_score_hypotheses_range(const double *Rt_dev, int n_sets, int H_total,
+                                int h_begin, int H, const int32_t *skip_dev,
+                                const double *K_host, const double *t_right_host,
+                                const double *X_dev, const double *Y_dev,
+                                const double *Z_dev, const float *uL_dev,
+                                const float *vL_dev, const float *uR_dev,
+                                const float *vR_dev, int cap, const int32_t *n_dev,
+                                int n_host, double thresh, int32_t *counts_dev,
+                                uint64_t *masks_dev, int mask_words,
+                                double *work_dev, void *stream);
+
+/*
  * Winner of a scored hypothesis set: the FIRST hypothesis with the largest
  * supporter count, as ransac_for_pnp's strict '>' update keeps it
  * (utils/utils.py:438-442) when every hypothesis is consumed.
@@ -289,31 +308,38 @@ int slam_ransac_sample(uint64_t seed, int n_sets, int H, const int32_t *n_dev,
  * (utils/utils.py:428,481-497).  Three-point resection on the first three
  * correspondences of each sample (3-D point of the previous frame, left pixel of the
  * current frame), the fourth correspondence picks among the solutions.
- * Rt [n_sets, H, 12] f64 dev, 16-byte aligned; a failed solve (the reference's None)
- * is written as NaNs, which slam_score_hypotheses counts as 0 supporters.
+ * samples [n_sets, H_total, 4], Rt [n_sets, H_total, 12] f64 dev, 16-byte aligned; only
+ * hypotheses [h_begin, h_begin + H) of the sets whose skip_dev entry (nullable array) is zero
+ * are solved.  A failed solve (the reference's None) is written as NaNs, which
+ * slam_score_hypotheses counts as 0 supporters.
  * K must be a pinhole matrix [fx 0 cx; 0 fy cy; 0 0 1].
  */
 int slam_p3p_hypotheses(const double *K_host, const double *X_dev,
                         const double *Y_dev, const double *Z_dev,
                         const float *uL_dev, const float *vL_dev, int cap,
                         const int32_t *n_dev, int n_host,
-                        const int32_t *samples_dev, int n_sets, int H,
+                        const int32_t *samples_dev, int n_sets, int H_total,
+                        int h_begin, int H, const int32_t *skip_dev,
                         double *Rt_dev, void *stream);
 
 /*
  * The sampling loop's control flow (utils/utils.py:422-446, 475-478) replayed over the
- * supporter counts of hypotheses 0..min(H, max_iterations)-1 taken in order:
+ * supporter counts of hypotheses 0..min(H, max_iterations, n_avail)-1 taken in order
+ * (n_avail = how many hypotheses per set have been scored so far; H = row stride):
  * strict '>' best update, epsilon = min(epsilon, 1 - count/n), I = min(ceil(log(1-0.999)
  * / log(1-(1-epsilon)^4)), max_iterations), stop when i >= I or epsilon == 0.
  * best [n_sets] = index of the winner (-1: no hypothesis had a supporter),
  * best_count, best_Rt [n_sets, 12] (NaN without winner), iters [n_sets] = iterations the
  * loop would have run (nullable).  Sets with n < 4 get -1 / 0 iterations.
+ * stopped [n_sets] (nullable) = 1 where the loop is over -- the rule fired within the
+ * hypotheses available, or min(H, max_iterations) of them were consumed -- and 0 where more
+ * hypotheses have to be scored before the outcome is known.
  */
 int slam_ransac_select(const int32_t *counts_dev, const double *Rt_dev, int n_sets,
-                       int H, const int32_t *n_dev, int n_host, int cap,
+                       int H, int n_avail, const int32_t *n_dev, int n_host, int cap,
                        int max_iterations, int32_t *best_dev,
                        int32_t *best_count_dev, double *best_Rt_dev,
-                       int32_t *iters_dev, void *stream);
+                       int32_t *iters_dev, int32_t *stopped_dev, void *stream);
 
 /*
  * Refinement of each winner on its supporters: replaces

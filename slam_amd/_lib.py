@@ -23,6 +23,7 @@ EXPORTS = (
     "slam_triangulate_matched",
     "slam_join_consensus",
     "slam_score_hypotheses",
+    "slam_score_hypotheses_range",
     "slam_select_best",
     "slam_build_inlier_tables",
     "slam_ransac_sample",
@@ -78,6 +79,9 @@ def load():
     lib.slam_join_consensus.argtypes = [vp, ci, ci] + [vp] * 11 + [ci] + [vp] * 9 + [vp]
     lib.slam_score_hypotheses.restype = ci
     lib.slam_score_hypotheses.argtypes = [vp, ci, ci, vp, vp] + [vp] * 7 + [ci, vp, ci, cd, vp, vp, ci, vp, vp]
+    lib.slam_score_hypotheses_range.restype = ci
+    lib.slam_score_hypotheses_range.argtypes = ([vp, ci, ci, ci, ci, vp, vp, vp] + [vp] * 7 +
+                                                [ci, vp, ci, cd, vp, vp, ci, vp, vp])
     lib.slam_select_best.restype = ci
     lib.slam_select_best.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
     lib.slam_build_inlier_tables.restype = ci
@@ -85,9 +89,9 @@ def load():
     lib.slam_ransac_sample.restype = ci
     lib.slam_ransac_sample.argtypes = [ctypes.c_uint64, ci, ci, vp, ci, vp, vp]
     lib.slam_p3p_hypotheses.restype = ci
-    lib.slam_p3p_hypotheses.argtypes = [vp] * 6 + [ci, vp, ci, vp, ci, ci, vp, vp]
+    lib.slam_p3p_hypotheses.argtypes = [vp] * 6 + [ci, vp, ci, vp, ci, ci, ci, ci, vp, vp, vp]
     lib.slam_ransac_select.restype = ci
-    lib.slam_ransac_select.argtypes = [vp, vp, ci, ci, vp, ci, ci, ci, vp, vp, vp, vp, vp]
+    lib.slam_ransac_select.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp]
     lib.slam_refine_poses.restype = ci
     lib.slam_refine_poses.argtypes = [vp] * 6 + [ci, vp, ci, vp, ci, vp, ci, ci, vp, vp, vp]
     lib.slam_ransac_adopt.restype = ci

@@ -179,7 +179,9 @@ struct P3PArgs {
     const int32_t *n_dev;
     int n_host;
     const int32_t *samples;
-    int n_sets, H;
+    int n_sets, H;     // hypotheses solved per set
+    int Hs, h0;        // hypotheses per set in memory, first one solved
+    const int32_t *skip;
     double *Rt;
 };
 
@@ -189,10 +191,13 @@ struct P3PArgs {
 // supports nothing, which is what skipping the iteration amounts to in the stopping rule.
 __global__ void __launch_bounds__(256) p3p_kernel(const P3PArgs a)
 {
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= (long long)a.n_sets * a.H)
+    const long long lid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (lid >= (long long)a.n_sets * a.H)
         return;
-    const int set = (int)(gid / a.H);
+    const int set = (int)(lid / a.H);
+    if (a.skip && a.skip[set])
+        return;
+    const long long gid = (long long)set * a.Hs + a.h0 + (lid - (long long)set * a.H);
     const double nan = __builtin_nan("");
     double out[12];
 #pragma unroll
@@ -328,11 +333,12 @@ __device__ __forceinline__ int iterations_needed(double eps, int max_it)
 // have run, iters = how many it would have run.  A count of 0 leaves eps and I unchanged, exactly
 // like an iteration whose minimal solve failed.
 __global__ void __launch_bounds__(256) ransac_select_kernel(const int32_t *__restrict__ counts,
-                                                            const double *__restrict__ Rt, int H,
+                                                            const double *__restrict__ Rt, int H, int n_avail,
                                                             const int32_t *__restrict__ n_dev, int n_host, int cap,
                                                             int max_it, int32_t *__restrict__ best,
                                                             int32_t *__restrict__ best_count,
-                                                            double *__restrict__ best_Rt, int32_t *__restrict__ iters)
+                                                            double *__restrict__ best_Rt, int32_t *__restrict__ iters,
+                                                            int32_t *__restrict__ stopped_out)
 {
     __shared__ unsigned long long wave_key[4];
     __shared__ int stop_at[4];
@@ -343,7 +349,7 @@ __global__ void __launch_bounds__(256) ransac_select_kernel(const int32_t *__res
     int n = n_dev ? n_dev[set] : n_host;
     n = min(max(n, 0), cap);
     const int32_t *c = counts + (size_t)set * H;
-    const int limit = min(H, max_it);
+    const int limit = min(min(H, max_it), n_avail);   // hypotheses scored so far, at most the loop's cap
     // key orders by count descending, then index ascending; 0 = nothing yet
     unsigned long long carry = 0ull;
     int total_iters = (n >= 4) ? limit : 0;
@@ -411,6 +417,9 @@ __global__ void __launch_bounds__(256) ransac_select_kernel(const int32_t *__res
         best_count[set] = bc;
         if (iters)
             iters[set] = total_iters;
+        // the loop is over for this set: the rule fired, or the cap itself was reached, or n < 4
+        if (stopped_out)
+            stopped_out[set] = (stopped || limit >= min(H, max_it)) ? 1 : 0;
     }
     if (tid < 12 && best_Rt)
         best_Rt[(size_t)set * 12 + tid] = bh >= 0 ? Rt[((size_t)set * H + bh) * 12 + tid] : __builtin_nan("");
@@ -753,10 +762,14 @@ static bool pinhole(const double *K)
 
 extern "C" int slam_p3p_hypotheses(const double *K, const double *X, const double *Y, const double *Z,
                                    const float *uL, const float *vL, int cap, const int32_t *n_dev, int n_host,
-                                   const int32_t *samples, int n_sets, int H, double *Rt, void *stream)
+                                   const int32_t *samples, int n_sets, int H_total, int h_begin, int H,
+                                   const int32_t *skip, double *Rt, void *stream)
 {
-    if (n_sets < 0 || H < 0 || cap < 0)
+    if (n_sets < 0 || H < 0 || cap < 0 || h_begin < 0 || H_total < 0)
         return fail(SLAM_ERR_BAD_ARG, "slam_p3p_hypotheses: negative size");
+    if ((long long)h_begin + H > H_total)
+        return fail(SLAM_ERR_BAD_ARG, "slam_p3p_hypotheses: range [%d, %d) exceeds %d hypotheses per set", h_begin,
+                    h_begin + H, H_total);
     if (!K)
         return fail(SLAM_ERR_BAD_ARG, "slam_p3p_hypotheses: null intrinsics");
     if (!pinhole(K))
@@ -783,6 +796,9 @@ extern "C" int slam_p3p_hypotheses(const double *K, const double *X, const doubl
     a.samples = samples;
     a.n_sets = n_sets;
     a.H = H;
+    a.Hs = H_total;
+    a.h0 = h_begin;
+    a.skip = skip;
     a.Rt = Rt;
     const long long total = (long long)n_sets * H;
     const long long blocks = (total + 255) / 256;
@@ -792,18 +808,19 @@ extern "C" int slam_p3p_hypotheses(const double *K, const double *X, const doubl
     return check_launch("slam_p3p_hypotheses");
 }
 
-extern "C" int slam_ransac_select(const int32_t *counts, const double *Rt, int n_sets, int H, const int32_t *n_dev,
-                                  int n_host, int cap, int max_iterations, int32_t *best, int32_t *best_count,
-                                  double *best_Rt, int32_t *iters, void *stream)
+extern "C" int slam_ransac_select(const int32_t *counts, const double *Rt, int n_sets, int H, int n_avail,
+                                  const int32_t *n_dev, int n_host, int cap, int max_iterations, int32_t *best,
+                                  int32_t *best_count, double *best_Rt, int32_t *iters, int32_t *stopped,
+                                  void *stream)
 {
-    if (n_sets < 0 || H < 0 || max_iterations < 0)
+    if (n_sets < 0 || H < 0 || max_iterations < 0 || n_avail < 0)
         return fail(SLAM_ERR_BAD_ARG, "slam_ransac_select: negative size");
     if (n_sets == 0)
         return SLAM_OK;
     if (!counts || !best || !best_count || (best_Rt && !Rt))
         return fail(SLAM_ERR_BAD_ARG, "slam_ransac_select: null buffer");
-    hipLaunchKernelGGL(ransac_select_kernel, dim3(n_sets), dim3(256), 0, (hipStream_t)stream, counts, Rt, H, n_dev,
-                       n_host, cap, max_iterations, best, best_count, best_Rt, iters);
+    hipLaunchKernelGGL(ransac_select_kernel, dim3(n_sets), dim3(256), 0, (hipStream_t)stream, counts, Rt, H, n_avail,
+                       n_dev, n_host, cap, max_iterations, best, best_count, best_Rt, iters, stopped);
     return check_launch("slam_ransac_select");
 }
 

@@ -67,7 +67,9 @@ __device__ __forceinline__ bool supports(const double *__restrict__ rt, const Ma
 
 struct ScoreArgs {
     const double *Rt;
-    int H;
+    int H;             // hypotheses scored per set
+    int Hs;            // hypotheses per set in memory (row stride of Rt, counts and masks)
+    const int32_t *skip;   // nullable: sets with a non-zero entry are left untouched
     Mat33 K;
     Vec3 tr;
     const double *X, *Y, *Z;
@@ -94,7 +96,7 @@ __global__ void __launch_bounds__(256) score_kernel(const ScoreArgs a)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h0 = (blk * 4 + wave) * SCORE_HPW;
-    if (h0 >= a.H)
+    if (h0 >= a.H || (a.skip && a.skip[set]))
         return;
     int n = a.n_dev ? a.n_dev[set] : a.n_host;
     n = min(max(n, 0), a.cap);
@@ -104,7 +106,7 @@ __global__ void __launch_bounds__(256) score_kernel(const ScoreArgs a)
 #pragma unroll
     for (int e = 0; e < SCORE_HPW; ++e) {
         live[e] = (h0 + e) < a.H;
-        const double *src = a.Rt + ((size_t)set * a.H + (live[e] ? h0 + e : h0)) * 12;
+        const double *src = a.Rt + ((size_t)set * a.Hs + (live[e] ? h0 + e : h0)) * 12;
 #pragma unroll
         for (int c = 0; c < 12; ++c)
             rt[e][c] = src[c];
@@ -125,14 +127,14 @@ __global__ void __launch_bounds__(256) score_kernel(const ScoreArgs a)
             const unsigned long long m = __ballot(s);
             cnt[e] += __popcll(m);
             if (a.masks && live[e] && lane == 0)
-                a.masks[((size_t)set * a.H + h0 + e) * a.mask_words + (base >> 6)] = m;
+                a.masks[((size_t)set * a.Hs + h0 + e) * a.mask_words + (base >> 6)] = m;
         }
     }
     if (lane == 0) {
 #pragma unroll
         for (int e = 0; e < SCORE_HPW; ++e)
             if (live[e])
-                a.counts[(size_t)set * a.H + h0 + e] = cnt[e];
+                a.counts[(size_t)set * a.Hs + h0 + e] = cnt[e];
     }
 }
 
@@ -191,6 +193,8 @@ __global__ void __launch_bounds__(256) score_prep_kernel(const ScoreArgs a, int 
     __shared__ unsigned long long red[3][4];
     const int set = blockIdx.x / chunks_per_set;
     const int chunk = blockIdx.x - set * chunks_per_set;
+    if (a.skip && a.skip[set])
+        return;
     int n = a.n_dev ? a.n_dev[set] : a.n_host;
     n = min(max(n, 0), a.cap);
     const int i = chunk * 256 + threadIdx.x;
@@ -333,12 +337,12 @@ __global__ void __launch_bounds__(256) score_fast_kernel(const ScoreArgs a)
     const int set = blockIdx.x / a.blocks_per_set;
     const int blk = blockIdx.x - set * a.blocks_per_set;
     const int h = blk * 256 + threadIdx.x;
-    if ((blk * 256 + (int)(threadIdx.x & ~63u)) >= a.H)
-        return;  // whole wavefront past the last hypothesis
+    if ((blk * 256 + (int)(threadIdx.x & ~63u)) >= a.H || (a.skip && a.skip[set]))
+        return;  // whole wavefront past the last hypothesis, or a set that is not to be scored
     const bool live = h < a.H;
     const double *hdr = score_hdr(a) + SCORE_HDR * set;
     Lane64 L;
-    L.setup(a, a.Rt + ((size_t)set * a.H + (live ? h : a.H - 1)) * 12, hdr[0], hdr[1]);
+    L.setup(a, a.Rt + ((size_t)set * a.Hs + (live ? h : a.H - 1)) * 12, hdr[0], hdr[1]);
 
     int n = a.n_dev ? a.n_dev[set] : a.n_host;
     n = min(max(n, 0), a.cap);
@@ -380,7 +384,7 @@ __global__ void __launch_bounds__(256) score_fast_kernel(const ScoreArgs a)
         }
     }
     if (live)
-        a.counts[(size_t)set * a.H + h] = cnt;
+        a.counts[(size_t)set * a.Hs + h] = cnt;
 }
 
 // Mixed-precision kernel for rectified stereo: lane = hypothesis, points through scalar
@@ -407,12 +411,12 @@ __global__ void __launch_bounds__(256) score_mixed_kernel(const ScoreArgs a)
     const int set = blockIdx.x / a.blocks_per_set;
     const int blk = blockIdx.x - set * a.blocks_per_set;
     const int h = blk * 256 + threadIdx.x;
-    if ((blk * 256 + (int)(threadIdx.x & ~63u)) >= a.H)
-        return;  // whole wavefront past the last hypothesis
+    if ((blk * 256 + (int)(threadIdx.x & ~63u)) >= a.H || (a.skip && a.skip[set]))
+        return;  // whole wavefront past the last hypothesis, or a set that is not to be scored
     const bool live = h < a.H;
     const double *hdr = score_hdr(a) + SCORE_HDR * set;
     const double Amax = hdr[0], Umax = hdr[1], Wmax = hdr[2];
-    const double *pose = a.Rt + ((size_t)set * a.H + (live ? h : a.H - 1)) * 12;
+    const double *pose = a.Rt + ((size_t)set * a.Hs + (live ? h : a.H - 1)) * 12;
 
     // ---- fp32 lane constants ----------------------------------------------------------
     // The fp64 lane state is only needed to settle undecided points after the loop; it is
@@ -607,7 +611,7 @@ __global__ void __launch_bounds__(256) score_mixed_kernel(const ScoreArgs a)
     if (dead)
         cnt = 0;
     if (live)
-        a.counts[(size_t)set * a.H + h] = cnt;
+        a.counts[(size_t)set * a.Hs + h] = cnt;
 }
 
 }  // namespace
@@ -621,8 +625,24 @@ extern "C" int slam_score_hypotheses(const double *Rt, int n_sets, int H, const 
                                      int n_host, double thresh, int32_t *counts, uint64_t *masks, int mask_words,
                                      double *work, void *stream)
 {
-    if (n_sets < 0 || H < 0 || cap < 0)
+    return slam_score_hypotheses_range(Rt, n_sets, H, 0, H, nullptr, K, t_right, X, Y, Z, uL, vL, uR, vR, cap, n_dev,
+                                       n_host, thresh, counts, masks, mask_words, work, stream);
+}
+
+extern "C" int slam_score_hypotheses_range(const double *Rt, int n_sets, int H_total, int h_begin, int H,
+                                           const int32_t *skip, const double *K, const double *t_right,
+                                           const double *X, const double *Y, const double *Z, const float *uL,
+                                           const float *vL, const float *uR, const float *vR, int cap,
+                                           const int32_t *n_dev, int n_host, double thresh, int32_t *counts,
+                                           uint64_t *masks, int mask_words, double *work, void *stream)
+{
+    if (n_sets < 0 || H < 0 || cap < 0 || h_begin < 0 || H_total < 0)
         return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: negative size");
+    if ((long long)h_begin + H > H_total)
+        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses_range: range [%d, %d) exceeds %d hypotheses per set",
+                    h_begin, h_begin + H, H_total);
+    if (masks && (h_begin != 0 || H != H_total || skip))
+        return fail(SLAM_ERR_UNSUPPORTED, "slam_score_hypotheses_range: masks need the full range and no skip list");
     if (!K || !t_right)
         return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: null intrinsics");
     if (n_sets == 0 || H == 0)
@@ -637,8 +657,10 @@ extern "C" int slam_score_hypotheses(const double *Rt, int n_sets, int H, const 
     if ((reinterpret_cast<uintptr_t>(Rt) | reinterpret_cast<uintptr_t>(work)) & 15)
         return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: Rt and work must be 16-byte aligned");
     ScoreArgs a;
-    a.Rt = Rt;
+    a.Rt = Rt ? Rt + (size_t)h_begin * 12 : Rt;
     a.H = H;
+    a.Hs = H_total;
+    a.skip = skip;
     for (int i = 0; i < 9; ++i)
         a.K.m[i] = K[i];
     a.trmax = 0.0;
@@ -658,7 +680,7 @@ extern "C" int slam_score_hypotheses(const double *Rt, int n_sets, int H, const 
     a.n_dev = n_dev;
     a.n_host = n_host;
     a.thresh = thresh;
-    a.counts = counts;
+    a.counts = counts ? counts + h_begin : counts;
     a.masks = reinterpret_cast<unsigned long long *>(masks);
     a.mask_words = mask_words;
     a.work = work;

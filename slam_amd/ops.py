@@ -304,14 +304,15 @@ def p3p_hypotheses(K, X, Y, Z, uL, vL, cap, n_dev, samples):
     st = lib.slam_p3p_hypotheses(Kp, _dev(X, torch.float64, "X"), _dev(Y, torch.float64, "Y"),
                                  _dev(Z, torch.float64, "Z"), _dev(uL, torch.float32, "uL"),
                                  _dev(vL, torch.float32, "vL"), int(cap), _dev(n_dev, torch.int32, "n_dev"), 0,
-                                 _dev(samples, torch.int32, "samples"), n_sets, H, ctypes.c_void_p(out.data_ptr()),
-                                 _stream())
+                                 _dev(samples, torch.int32, "samples"), n_sets, H, 0, H, ctypes.c_void_p(0),
+                                 ctypes.c_void_p(out.data_ptr()), _stream())
     _lib.check(st, "slam_p3p_hypotheses")
     return out[:n_sets, :H]
 
 
-def ransac_select(counts, Rt, n_dev, cap, max_iterations):
-    """(best, best_count, best_Rt, iters) of the stopping rule replayed over counts [n_sets, H]."""
+def ransac_select(counts, Rt, n_dev, cap, max_iterations, n_avail=None, want_stopped=False):
+    """(best, best_count, best_Rt, iters[, stopped]) of the stopping rule replayed over the first
+    n_avail (default all) columns of counts [n_sets, H]."""
     lib = _lib.load()
     n_sets, H = counts.shape
     dev = counts.device
@@ -319,11 +320,15 @@ def ransac_select(counts, Rt, n_dev, cap, max_iterations):
     best_count = torch.empty_like(best)
     iters = torch.empty_like(best)
     best_Rt = torch.empty((max(n_sets, 1), 12), dtype=torch.float64, device=dev)
+    stopped = torch.empty_like(best)
     st = lib.slam_ransac_select(_dev(counts, torch.int32, "counts"), _dev(Rt, torch.float64, "Rt"), n_sets, H,
-                                _dev(n_dev, torch.int32, "n_dev"), 0, int(cap), int(max_iterations),
-                                ctypes.c_void_p(best.data_ptr()), ctypes.c_void_p(best_count.data_ptr()),
-                                ctypes.c_void_p(best_Rt.data_ptr()), ctypes.c_void_p(iters.data_ptr()), _stream())
+                                H if n_avail is None else int(n_avail), _dev(n_dev, torch.int32, "n_dev"), 0, int(cap),
+                                int(max_iterations), ctypes.c_void_p(best.data_ptr()),
+                                ctypes.c_void_p(best_count.data_ptr()), ctypes.c_void_p(best_Rt.data_ptr()),
+                                ctypes.c_void_p(iters.data_ptr()), ctypes.c_void_p(stopped.data_ptr()), _stream())
     _lib.check(st, "slam_ransac_select")
+    if want_stopped:
+        return best[:n_sets], best_count[:n_sets], best_Rt[:n_sets], iters[:n_sets], stopped[:n_sets]
     return best[:n_sets], best_count[:n_sets], best_Rt[:n_sets], iters[:n_sets]
 
 

@@ -230,6 +230,7 @@ class FrontEnd:
         ws.samples = torch.empty((np_, ws.H, 4), dtype=torch.int32, device=dev)
         ws.Rt_gen = torch.empty((np_, ws.H, 12), dtype=torch.float64, device=dev)
         ws.iters = torch.zeros(np_, dtype=torch.int32, device=dev)
+        ws.stopped = torch.zeros(np_, dtype=torch.int32, device=dev)
         ws.ref_Rt = torch.empty((np_, 12), dtype=torch.float64, device=dev)
         ws.ref_ok = torch.zeros(np_, dtype=torch.int32, device=dev)
         ws.ratio = torch.empty(np_, dtype=torch.float64, device=dev)
@@ -257,23 +258,50 @@ class FrontEnd:
                                                _p(ws.n_inl), stream)
         _lib.check(st, "slam_build_inlier_tables")
 
-    def ransac(self, ws, seed, stream, max_iterations=None, refine_iterations=30):
+    def ransac(self, ws, seed, stream, max_iterations=None, refine_iterations=30, first_slice=128):
         """PnP-RANSAC of every pair on the device (utils/utils.py:413-464): H minimal samples
         per pair from a generator keyed by (seed, pair, hypothesis), P3P, supporter counts, the
         stopping rule replayed over the counts, refinement of the winner on its supporters,
-        the refined pose's supporters as the inlier tables.  Results: ws.pose [P,12],
+        the refined pose's supporters as the inlier tables.  first_slice: hypotheses scored for
+        every pair before the rule is consulted (0: score all at once).  Results: ws.pose [P,12],
         ws.ratio [P], ws.found [P], ws.iters [P], ws.best_count [P], the inlier tables."""
         c = ws.cons
         max_it = ws.H if max_iterations is None else int(max_iterations)
         lib = self.lib
         _lib.check(lib.slam_ransac_sample(ctypes.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), ws.P, ws.H, _p(c.count), 0,
                                           _p(ws.samples), stream), "slam_ransac_sample")
-        _lib.check(lib.slam_p3p_hypotheses(ws.hK, _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL), _p(c.vL), ws.cap, _p(c.count), 0,
-                                           _p(ws.samples), ws.P, ws.H, _p(ws.Rt_gen), stream), "slam_p3p_hypotheses")
-        self.score(ws, ws.Rt_gen, stream)
-        _lib.check(lib.slam_ransac_select(_p(ws.counts), _p(ws.Rt_gen), ws.P, ws.H, _p(c.count), 0, ws.cap, max_it,
-                                          _p(ws.best), _p(ws.best_count), _p(ws.best_Rt), _p(ws.iters), stream),
-                   "slam_ransac_select")
+
+        def solve_range(h0, hn, skip):
+            st = lib.slam_p3p_hypotheses(ws.hK, _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL), _p(c.vL), ws.cap, _p(c.count), 0,
+                                         _p(ws.samples), ws.P, ws.H, h0, hn, _p(skip), _p(ws.Rt_gen), stream)
+            _lib.check(st, "slam_p3p_hypotheses")
+
+        def score_range(h0, hn, skip):
+            st = lib.slam_score_hypotheses_range(_p(ws.Rt_gen), ws.P, ws.H, h0, hn, _p(skip), ws.hK, ws.hT, _p(c.X),
+                                                 _p(c.Y), _p(c.Z), _p(c.uL), _p(c.vL), _p(c.uR), _p(c.vR), ws.cap,
+                                                 _p(c.count), 0, self.pix_thresh, _p(ws.counts), None, 0,
+                                                 _p(ws.score_work), stream)
+            _lib.check(st, "slam_score_hypotheses_range")
+
+        def select(n_avail):
+            st = lib.slam_ransac_select(_p(ws.counts), _p(ws.Rt_gen), ws.P, ws.H, n_avail, _p(c.count), 0, ws.cap,
+                                        max_it, _p(ws.best), _p(ws.best_count), _p(ws.best_Rt), _p(ws.iters),
+                                        _p(ws.stopped), stream)
+            _lib.check(st, "slam_ransac_select")
+
+        # The stopping rule usually ends the loop within the first few dozen hypotheses (about
+        # 6 at 98 % inliers, about 100 at 50 %): score a first slice for every pair, apply the
+        # rule, and score the rest only for the pairs it has not stopped yet.  The outcome is the
+        # one of scoring everything: the rule never looks past the iteration it stops at.
+        n_used = min(ws.H, max_it)
+        first = min(int(first_slice), n_used) if first_slice else n_used
+        solve_range(0, first, None)
+        score_range(0, first, None)
+        select(first)
+        if first < n_used:
+            solve_range(first, n_used - first, ws.stopped)
+            score_range(first, n_used - first, ws.stopped)
+            select(n_used)
         self._score_one(ws, ws.best_Rt, stream)
         _lib.check(lib.slam_refine_poses(ws.hK, _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL), _p(c.vL), ws.cap, _p(c.count), 0,
                                          _p(ws.final_mask), max(ws.mask_words, 1), _p(ws.best_Rt), ws.P,
@@ -285,7 +313,7 @@ class FrontEnd:
                                          stream), "slam_ransac_adopt")
         self._tables(ws, stream)
 
-    def run_ransac(self, ws, seed, max_iterations=None):
+    def run_ransac(self, ws, seed, max_iterations=None, first_slice=128):
         """Stages 1-4 followed by the device-side RANSAC, all on the current stream."""
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         if ws.F == 0:
@@ -297,7 +325,7 @@ class FrontEnd:
         if ws.P > 0:
             self.temporal_match(ws, stream)
             self.join(ws, stream)
-            self.ransac(ws, seed, stream, max_iterations=max_iterations)
+            self.ransac(ws, seed, stream, max_iterations=max_iterations, first_slice=first_slice)
         return ws
 
     def run(self, ws, Rt=None):

@@ -120,6 +120,15 @@ def test_stopping_rule_replay_matches_the_twin(device):
             continue
         want_best, want_iters = twin.ransac_stop_replay(c[:min(H, max_it)], n, min(H, max_it))
         assert (int(best[0]), int(iters[0])) == (want_best, want_iters), (n, H, max_it)
+        # with only a first slice of the hypotheses available: either the rule has already fired
+        # (then the answer is final) or the set is reported unfinished
+        for avail in (1, 5, 100):
+            b2, _, _, it2, stopped = ops.ransac_select(_t(c[None], device), Rt, _t(np.array([n], np.int32), device), n,
+                                                       max_it, n_avail=avail, want_stopped=True)
+            if want_iters < min(avail, H, max_it) or avail >= min(H, max_it):
+                assert int(stopped[0]) == 1 and (int(b2[0]), int(it2[0])) == (want_best, want_iters), (n, H, max_it, avail)
+            elif want_iters > avail:
+                assert int(stopped[0]) == 0 and int(it2[0]) == avail
         if want_best >= 0:
             assert int(bc[0]) == c[want_best]
             assert torch.equal(bRt[0], Rt[0, want_best])
@@ -165,8 +174,18 @@ def test_device_ransac_end_to_end(device):
     fe = pipeline.FrontEnd(k, m1, m2)
     tb = pipeline.FrameTables.from_frames(seq.frames, device)
     ws = fe.prepare(tb, n_hyp=H)
-    fe.run_ransac(ws, seed=6)
+    # two-phase scoring (a first slice for all pairs, the rest only where the rule has not fired)
+    # must give what scoring everything gives
+    fe.run_ransac(ws, seed=6, first_slice=32)
     torch.cuda.synchronize()
+    two_phase = {n: getattr(ws, n).clone() for n in ("best", "best_count", "iters", "pose", "ratio", "found", "n_inl")}
+    two_phase["rows"] = ws.inl_rows[:int(ws.n_inl.sum())].clone()
+    assert int(ws.stopped.sum()) == P
+    fe.run_ransac(ws, seed=6, first_slice=0)
+    torch.cuda.synchronize()
+    for n, v in two_phase.items():
+        got = ws.inl_rows[:int(ws.n_inl.sum())] if n == "rows" else getattr(ws, n)
+        assert torch.equal(v, got, ) if v.dtype != torch.float64 else np.array_equal(v.cpu().numpy(), got.cpu().numpy(), equal_nan=True), n
     cons = pipeline.consensus_to_host(ws)
     counts = ws.counts.cpu().numpy()
     samples = ws.samples.cpu().numpy()

@@ -28,15 +28,17 @@ for H in (1000, 10000):
     stages = {
         "sample": lambda: lib.slam_ransac_sample(ctypes.c_uint64(6), ws.P, ws.H, _p(c.count), 0, _p(ws.samples), stream),
         "p3p": lambda: lib.slam_p3p_hypotheses(ws.hK, _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL), _p(c.vL), ws.cap, _p(c.count), 0,
-                                               _p(ws.samples), ws.P, ws.H, _p(ws.Rt_gen), stream),
+                                               _p(ws.samples), ws.P, ws.H, 0, ws.H, None, _p(ws.Rt_gen), stream),
         "score": lambda: fe.score(ws, ws.Rt_gen, stream),
-        "select": lambda: lib.slam_ransac_select(_p(ws.counts), _p(ws.Rt_gen), ws.P, ws.H, _p(c.count), 0, ws.cap, H,
-                                                 _p(ws.best), _p(ws.best_count), _p(ws.best_Rt), _p(ws.iters), stream),
+        "select": lambda: lib.slam_ransac_select(_p(ws.counts), _p(ws.Rt_gen), ws.P, ws.H, ws.H, _p(c.count), 0, ws.cap, H,
+                                                 _p(ws.best), _p(ws.best_count), _p(ws.best_Rt), _p(ws.iters),
+                                                 _p(ws.stopped), stream),
         "score_one": lambda: fe._score_one(ws, ws.best_Rt, stream),
         "refine": lambda: lib.slam_refine_poses(ws.hK, _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL), _p(c.vL), ws.cap, _p(c.count), 0,
                                                 _p(ws.final_mask), max(ws.mask_words, 1), _p(ws.best_Rt), ws.P, 30,
                                                 _p(ws.ref_Rt), _p(ws.ref_ok), stream),
         "tables": lambda: fe._tables(ws, stream),
+        "whole_ransac_one_phase": lambda: fe.ransac(ws, 6, stream, first_slice=0),
         "whole_ransac": lambda: fe.ransac(ws, 6, stream),
         "whole_front_end": lambda: fe.run_ransac(ws, 6),
     }
