@@ -90,3 +90,25 @@ def test_2k_keypoints_frame_range(device):
 
 def test_8k_keypoints_stress(device):
     _check_frame_range(device, 8000, 3, 128, sample=48)
+
+
+def test_very_long_train_set(device):
+    """300 000 train rows against a handful of queries (the library's limit is 2^22 rows per
+    item): hundreds of key chunks, planted duplicates near the end, exact against the oracle."""
+    from slam_amd import ops
+    rng = np.random.default_rng(5)
+    D, nt, nq = 61, 300_000, 200
+    t = rng.integers(0, 256, (nt, D), dtype=np.uint8)
+    t[:, 60] &= 0x3F
+    q = rng.integers(0, 256, (nq, D), dtype=np.uint8)
+    q[:, 60] &= 0x3F
+    for i in range(50):                       # exact copies late in the scan, twice
+        t[nt - 1 - 2 * i] = q[i]
+        t[nt // 2 + 3 * i] = q[i]
+    tq = ops.pack_descriptors(torch.from_numpy(q).to(device), D)
+    tt = ops.pack_descriptors(torch.from_numpy(t).to(device), D)
+    seg = torch.tensor([[0, nq, 0, nt, 0]], dtype=torch.int32, device=device)
+    idx, dist, _ = ops.hamming_match(tq, tt, seg, nq, nt, D, k=2, n_rows=nq)
+    ridx, rdist = oracle.hamming_knn(q, t, 2, threads=8)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(dist.cpu().numpy(), rdist)
+    assert (ridx[:50, 0] == nt // 2 + 3 * np.arange(50)).all() and (rdist[:50] == 0).all()
