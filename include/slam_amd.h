@@ -214,7 +214,7 @@ int slam_join_consensus(const int32_t *pair_dev, int n_pairs, int max_nq,
  * A point supports iff both reprojection distances are < thresh (strict), all
  * in fp64 with one rounding per operation in the reference's order; no
  * cheirality test.
- * work_dev (nullable): caller-owned scratch of 16 * n_sets * max(cap, 1) doubles, 16-byte aligned.  When it
+ * work_dev (nullable): caller-owned scratch of 24 * n_sets * max(cap, 1) doubles, 16-byte aligned.  When it
  * is given, masks_dev is NULL and K is a pinhole matrix [fx 0 cx; 0 fy cy; 0 0 1],
  * evaluations are first run through a division-free filter and only the ones
  * within a guard band of the threshold are evaluated in the reference's order;

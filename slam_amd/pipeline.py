@@ -143,7 +143,7 @@ class FrontEnd:
         ws.mask_words = (ws.cap + 63) // 64
         ws.masks = (torch.zeros((max(ws.P, 1), max(ws.H, 1), max(ws.mask_words, 1)), dtype=torch.int64, device=dev)
                     if want_masks else None)
-        ws.score_work = f64(16 * max(ws.P * ws.cap, 1))
+        ws.score_work = f64(24 * max(ws.P * ws.cap, 1))
         # winner selection + inlier tables
         np_ = max(ws.P, 1)
         ws.best, ws.best_count = i32(np_), i32(np_)

@@ -23,13 +23,15 @@ def _rand_desc(rng, n, D):
 
 
 # --------------------------------------------------------------------------- knn
-@pytest.fixture(params=["mfma", "valu"], autouse=True)
+@pytest.fixture(params=["mfma", "valu", "bf16"], autouse=True)
 def kernel_impl(request, monkeypatch):
-    """Every test in this file runs against both implementations of the k-NN kernel (matrix-core
-    and VALU popcount) and of the filtered scoring kernel (fp32 first level and fp64 only); the
-    selectors are read on every call."""
-    monkeypatch.setenv("SLAM_KNN_IMPL", request.param)
-    monkeypatch.setenv("SLAM_SCORE_IMPL", "mixed" if request.param == "mfma" else "f64")
+    """Every test in this file runs against the implementations of the k-NN kernel (matrix-core,
+    VALU popcount) and of the filtered scoring kernel (fp32 first level on the VALU, fp64 only,
+    fp32 first level with the projections on the bf16 matrix cores); the selectors are read on
+    every call."""
+    knn, score = {"mfma": ("mfma", "mixed"), "valu": ("valu", "f64"), "bf16": ("mfma", "bf16")}[request.param]
+    monkeypatch.setenv("SLAM_KNN_IMPL", knn)
+    monkeypatch.setenv("SLAM_SCORE_IMPL", score)
     return request.param
 
 
