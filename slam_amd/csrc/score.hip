@@ -694,7 +694,10 @@ __device__ __forceinline__ uint32_t coef_slot(const uint32_t (&pc)[4][3], int k)
 
 __global__ void __launch_bounds__(256) score_mfma_kernel(const ScoreArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t stage[2][SM_STAGE_BYTES];
+    // two separate arrays, each named statically where it is used: the compiler then knows that a
+    // read of one does not have to wait for the copy in flight into the other
+    __shared__ __attribute__((aligned(16))) uint8_t stage0[SM_STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t stage1[SM_STAGE_BYTES];
     __shared__ unsigned queue[4][SM_QUEUE];     // per wavefront: (hypothesis row << 24) | point
     __shared__ int tally[4][32];
 
@@ -814,14 +817,14 @@ __global__ void __launch_bounds__(256) score_mfma_kernel(const ScoreArgs a)
     // stage: chunk (part, p) at (part * 128 + p) * 16 -- parts 0..3 the bf16 operand record of
     // point p, parts 4, 5 its fp32 record -- so that every tile read is 32 consecutive chunks.
     // Points past n re-read point n - 1; their results are masked or never computed.
-    auto load_stage = [&](int s, int buf) __attribute__((always_inline)) {
+    auto load_stage = [&](int s, uint8_t *to) __attribute__((always_inline)) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int idx = tid + 256 * c;          // 768 = 6 parts x 128 points
             const int part = idx >> 7, pt = idx & 127;
             const int gp = min(s * SM_STAGE + pt, n - 1);
             const uint8_t *src = part < 4 ? g16 + (size_t)gp * 64 + 16 * part : g32 + (size_t)gp * 32 + 16 * (part - 4);
-            uint8_t *dst = stage[buf] + (64 * wave + 256 * c) * 16;   // wave-uniform: the hardware adds lane * 16
+            uint8_t *dst = to + (64 * wave + 256 * c) * 16;   // wave-uniform: the hardware adds lane * 16
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         }
@@ -847,18 +850,18 @@ __global__ void __launch_bounds__(256) score_mfma_kernel(const ScoreArgs a)
     const int n_stages = (n + SM_STAGE - 1) / SM_STAGE;
     const bool run32 = any_live && !wave_exact;     // wave-uniform
     if (n_stages > 0)
-        load_stage(0, 0);
+        load_stage(0, stage0);
     __syncthreads();
-    for (int s = 0; s < n_stages; ++s) {
-        const int buf = s & 1;
+    // one stage: start the copy of the next one into `nxt`, work through the tiles of `cur`
+    auto do_stage = [&](int s, uint8_t *cur, uint8_t *nxt) __attribute__((always_inline)) {
         if (s + 1 < n_stages)
-            load_stage(s + 1, buf ^ 1);
+            load_stage(s + 1, nxt);
         if (run32) {
             // one tile of 32 points x the wavefront's 32 hypotheses; RAGGED: the tile may run past n
             auto do_tile = [&](int tile, auto ragged_tag) __attribute__((always_inline)) {
                 constexpr bool RAGGED = decltype(ragged_tag)::value;
                 const int gp = s * SM_STAGE + 32 * tile + col;
-                const uint8_t *pt = stage[buf] + (32 * tile + col) * 16;       // chunk of part 0
+                const uint8_t *pt = cur + (32 * tile + col) * 16;       // chunk of part 0
                 const uint4 b0 = *reinterpret_cast<const uint4 *>(pt + (0 + half) * 2048);
                 const uint4 b1 = *reinterpret_cast<const uint4 *>(pt + (2 + half) * 2048);
                 const float ul = *reinterpret_cast<const float *>(pt + 4 * 2048 + 12);
@@ -928,6 +931,11 @@ __global__ void __launch_bounds__(256) score_mfma_kernel(const ScoreArgs a)
                 flush();
         }
         __syncthreads();
+    };
+    for (int s = 0; s < n_stages; s += 2) {
+        do_stage(s, stage0, stage1);
+        if (s + 1 < n_stages)
+            do_stage(s + 1, stage1, stage0);
     }
     if (run32)
         flush();
