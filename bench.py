@@ -100,7 +100,10 @@ def main():
     local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # SLAM_BENCH_FORCE_DIST=1 takes the multi-rank path (process group, arena gather, overlap) even
+    # with one rank: the RCCL calls can then be exercised on a one-GPU box
+    multi = world > 1 or os.environ.get("SLAM_BENCH_FORCE_DIST", "0") == "1"
+    if multi:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -117,7 +120,7 @@ def main():
     fe = pipeline.FrontEnd(k, m1, m2, row_thresh=2.0, ratio_thresh=1.0, pix_thresh=2.0)
     tb = pipeline.FrameTables.from_frames(seq.frames, dev)
     cap_rows = P * int(np.diff(tb.offL).max())
-    table_pairs, table_rows = sharding.agree_table_shape(P, cap_rows, device=dev) if world > 1 else (P, cap_rows)
+    table_pairs, table_rows = sharding.agree_table_shape(P, cap_rows, device=dev) if multi else (P, cap_rows)
     ws = fe.prepare(tb, n_hyp=H, want_masks=False, table_pairs=table_pairs, table_rows=table_rows)
     Rt = torch.from_numpy(Rt_host).to(dev)
     # the step's launches are recorded once into a HIP graph and replayed (SLAM_BENCH_GRAPH=0: plain launches)
@@ -134,7 +137,7 @@ def main():
 
     graph = try_capture(ws)
     overlap = os.environ.get("SLAM_BENCH_OVERLAP", "1") != "0"
-    if world > 1:
+    if multi:
         # Two workspaces take turns so that the gather of step i (side stream, RCCL) overlaps the
         # kernels of step i+1; a workspace is reused only after its gather has finished.
         slots = [(ws, graph, sharding.TableGather(ws, world, rank))]
@@ -145,7 +148,7 @@ def main():
         step_no = [0]
 
     def step():
-        if world == 1:
+        if not multi:
             if graph is not None:
                 graph.replay()
             else:
@@ -177,7 +180,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -189,7 +192,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -237,7 +240,7 @@ def main():
         del ws_r
 
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         return
 
@@ -346,7 +349,7 @@ def main():
                                "sample": f"first {n_cpu} frame pairs of the same batch ({N} kp, {H} hypotheses), "
                                          f"C oracle with OpenMP over queries/points/hypotheses, {secs:.1f} s"}
     print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
