@@ -46,8 +46,9 @@ def make_segments(q_start, q_count, t_start, t_count, out_start, device):
     return torch.from_numpy(seg.astype(np.int32)).to(device)
 
 
-def pack_descriptors(desc, desc_bytes=None, dst_stride=None):
-    """[n, src_stride] uint8 -> [n, 32|64] uint8, zero padded (slam_pack_descriptors)."""
+def pack_descriptors(desc, desc_bytes=None, dst_stride=None, out=None):
+    """[n, src_stride] uint8 -> [n, 32|64] uint8, zero padded (slam_pack_descriptors).
+    out: an existing [n, dst_stride] uint8 table to fill instead of a new one."""
     lib = _lib.load()
     if desc.dim() != 2:
         raise ValueError("pack_descriptors: expected [n, bytes]")
@@ -55,7 +56,10 @@ def pack_descriptors(desc, desc_bytes=None, dst_stride=None):
     desc_bytes = src_stride if desc_bytes is None else int(desc_bytes)
     if dst_stride is None:
         dst_stride = 32 if desc_bytes <= 32 else 64
-    out = torch.empty((n, dst_stride), dtype=torch.uint8, device=desc.device)
+    if out is None:
+        out = torch.empty((n, dst_stride), dtype=torch.uint8, device=desc.device)
+    elif out.shape != (n, dst_stride) or out.dtype != torch.uint8 or not out.is_contiguous() or out.device != desc.device:
+        raise ValueError("pack_descriptors: out must be a contiguous [n, dst_stride] uint8 table on the input's device")
     st = lib.slam_pack_descriptors(_dev(desc, torch.uint8, "desc"), n, desc_bytes, src_stride,
                                    ctypes.c_void_p(out.data_ptr()), dst_stride, _stream())
     _lib.check(st, "slam_pack_descriptors")
