@@ -225,13 +225,11 @@ def _replay_into(db, poses, shards, frame):
         rows = sh["rows"][:T].cpu().numpy()
         loc = sh["loc"][:T].cpu().numpy()
         pose = sh["pose"].cpu().numpy().reshape(-1, 3, 4)
-        off = 0
+        db.update_tracks_from_pair_tables(frame, rows, loc, n_inl)
         for p in range(n_inl.shape[0]):
             m = int(n_inl[p])
-            db.update_tracks_from_tables(frame, rows[off:off + m], loc[off:off + m])
             db.add_inliers_ratio(frame, (m / int(n_cons[p])) if n_cons[p] else 0.0)
             db.add_num_matches(frame, num_matches=float(m))
             poses.append(pose[p])
-            off += m
             frame += 1
     return frame

@@ -11,10 +11,34 @@ Besides the reference's per-row entry point (`update_tracks_from_frame`, which a
 Matcher for pixel locations) there is `update_tracks_from_tables`, which consumes the
 inlier tables the GPU pipeline emits (rows [M,4] int32 + locations [M,6] float32).
 """
+import importlib.util
+import os
 import pickle
 import random
 
 import numpy as np
+
+
+def _load_native():
+    """The C helper built next to the GPU library (slam_amd/lib/_trackdb_native*.so); None when
+    it has not been built: the Python loop below does the same work, only slower."""
+    libdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
+    try:
+        names = [n for n in os.listdir(libdir) if n.startswith("_trackdb_native") and n.endswith(".so")]
+    except OSError:
+        return None
+    for n in names:
+        try:
+            spec = importlib.util.spec_from_file_location("_trackdb_native", os.path.join(libdir, n))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            return mod
+        except ImportError:
+            continue
+    return None
+
+
+_native = _load_native()
 
 SUCCESS, FAILURE = 0, 1
 LEFT, RIGHT = 0, 1
@@ -120,6 +144,27 @@ class TrackDatabase:
                 min_len = n
         self._max_length, self._min_length = max_len, min_len
         self._num_frames = len(self._frame_ids)
+
+    def update_tracks_from_pair_tables(self, first_frame, rows, loc, n_inl):
+        """The tables of consecutive frame pairs (first_frame, first_frame+1), ... in one call:
+        n_inl[p] rows of `rows`/`loc` belong to pair p, in frame order.  Same state as calling
+        update_tracks_from_tables pair by pair; done by the C helper when it is built."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        loc = np.ascontiguousarray(loc, dtype=np.float32)
+        n_inl = np.ascontiguousarray(n_inl, dtype=np.int64)
+        if _native is None:
+            off = 0
+            for p, m in enumerate(n_inl.tolist()):
+                self.update_tracks_from_tables(first_frame + p, rows[off:off + m], loc[off:off + m])
+                off += m
+            return
+        min_len = -1 if self._min_length == np.inf else int(self._min_length)
+        nf, nt, mx, mn, fr = _native.replay_pairs(self._tracks, self._frame_ids, self._last_insertions,
+                                                  int(first_frame), rows, loc, n_inl, int(self._next_free_trackId),
+                                                  int(self._num_tracks), int(self._max_length), min_len,
+                                                  int(self._num_frames))
+        self._next_free_trackId, self._num_tracks, self._max_length, self._num_frames = nf, nt, mx, fr
+        self._min_length = np.inf if mn < 0 else mn
 
     def add_inliers_ratio(self, frame_id, ratio):
         assert frame_id in self._frame_ids

@@ -1,0 +1,85 @@
+"""The C helper of the track store builds exactly the containers the Python loop builds."""
+import time
+
+import numpy as np
+import pytest
+
+from slam_amd import track_database
+from slam_amd.track_database import TrackDatabase
+
+
+def _tables(n_pairs, n_kp, seed, keep=0.7):
+    """Inlier tables with real track structure: a later-frame keypoint index of pair p shows up
+    as the earlier-frame index of pair p+1 for most rows; some indices repeat inside a pair."""
+    rng = np.random.default_rng(seed)
+    rows, loc, n_inl = [], [], []
+    prev_cur = rng.permutation(n_kp)[: n_kp // 2]
+    for _ in range(n_pairs):
+        m = int(rng.integers(0, n_kp // 2)) if rng.random() < 0.9 else 0
+        cont = prev_cur[rng.random(prev_cur.shape[0]) < keep][:m]
+        fresh = rng.integers(0, n_kp, size=m - cont.shape[0])
+        prev_left = np.concatenate([cont, fresh]).astype(np.int32)
+        rng.shuffle(prev_left)
+        cur_left = rng.integers(0, n_kp, size=m).astype(np.int32)      # collisions on purpose
+        r = np.stack([prev_left, rng.integers(0, n_kp, m), cur_left, rng.integers(0, n_kp, m)], axis=1).astype(np.int32)
+        rows.append(r)
+        loc.append(rng.uniform(0, 1200, size=(m, 6)).astype(np.float32))
+        n_inl.append(m)
+        prev_cur = cur_left if m else prev_cur
+    return np.concatenate(rows), np.concatenate(loc), np.asarray(n_inl, dtype=np.int64)
+
+
+def _python_replay(first, rows, loc, n_inl):
+    db = TrackDatabase()
+    off = 0
+    for p, m in enumerate(n_inl.tolist()):
+        db.update_tracks_from_tables(first + p, rows[off:off + m], loc[off:off + m])
+        off += m
+    return db
+
+
+@pytest.mark.skipif(track_database._native is None, reason="C helper not built")
+@pytest.mark.parametrize("first,n_pairs", [(0, 60), (7, 60), (0, 64), (3, 47)])
+def test_native_replay_equals_python_loop(first, n_pairs):
+    rows, loc, n_inl = _tables(n_pairs, 300, seed=3 + first + n_pairs)
+    if n_pairs == 64:
+        n_inl = np.concatenate([n_inl, [0, 0]])          # trailing pairs without rows
+    want = _python_replay(first, rows, loc, n_inl)
+    got = TrackDatabase()
+    # in two calls: the state carried between calls (parity slots, counters) must line up too
+    cut = 25
+    t0 = int(n_inl[:cut].sum())
+    got.update_tracks_from_pair_tables(first, rows[:t0], loc[:t0], n_inl[:cut])
+    got.update_tracks_from_pair_tables(first + cut, rows[t0:], loc[t0:], n_inl[cut:])
+    assert got == want
+    assert got.get_num_frames() == want.get_num_frames() and got.get_max_track() == want.get_max_track()
+    assert got.get_min_track() == want.get_min_track()
+    some = next(iter(want.get_trackIds()))
+    p_got, p_want = got.get_track_data(some)[0], want.get_track_data(some)[0]
+    assert [type(x) for x in p_got] == [type(x) for x in p_want] and type(p_got[1][0]) is float
+
+
+@pytest.mark.skipif(track_database._native is None, reason="C helper not built")
+def test_native_replay_empty_and_bad_input():
+    db = TrackDatabase()
+    db.update_tracks_from_pair_tables(0, np.zeros((0, 4), np.int32), np.zeros((0, 6), np.float32), np.zeros(3, np.int64))
+    assert db.get_num_tracks() == 0 and db.get_min_track() == np.inf and len(db.get_frameIds()) == 4
+    with pytest.raises(ValueError):
+        db.update_tracks_from_pair_tables(0, np.zeros((2, 4), np.int32), np.zeros((2, 6), np.float32), np.array([5]))
+
+
+@pytest.mark.skipif(track_database._native is None, reason="C helper not built")
+def test_native_replay_is_faster():
+    import gc
+    rows, loc, n_inl = _tables(300, 2000, seed=11)
+    gc.disable()
+    t0 = time.perf_counter()
+    want = _python_replay(0, rows, loc, n_inl)
+    t1 = time.perf_counter()
+    got = TrackDatabase()
+    got.update_tracks_from_pair_tables(0, rows, loc, n_inl)
+    t2 = time.perf_counter()
+    gc.enable()
+    assert got == want
+    print(f"python {t1 - t0:.3f} s, native {t2 - t1:.3f} s for {int(n_inl.sum())} rows")
+    assert (t2 - t1) < (t1 - t0)
