@@ -112,6 +112,29 @@ int slam_l2_match(const float *q_dev, const float *t_dev, const int32_t *seg_dev
                   void *stream);
 
 /*
+ * The same matcher for integer-valued descriptors -- what cv2's SIFT emits (float32 arrays holding
+ * integers 0..255; models/Matcher.py:15,111-119) -- on the int8 matrix cores.  Two steps:
+ *
+ * slam_l2_pack_int8: float32 [n, dim] -> int8 [n, dim] holding value - 128, norm2[n] = the squared
+ *   length of the shifted row, and *bad += the number of entries that are not integers in 0..255
+ *   (the caller zeroes *bad beforehand; a table with *bad != 0 must go through slam_l2_match).
+ *   Done once per descriptor table, like slam_pack_descriptors for the binary ones.
+ * slam_l2_match_int8: arguments as slam_l2_match, with the packed tables and their norms in
+ *   place of the float tables.  Indices, distances (sqrtf of the exact integer squared distance,
+ *   which is what cv2's float32 accumulation yields for such data) and keep flags are identical
+ *   to slam_l2_match on the float tables.
+ */
+int slam_l2_pack_int8(const float *desc_dev, int n, int dim, int8_t *out_dev,
+                      int32_t *norm2_dev, int32_t *bad_dev, void *stream);
+int slam_l2_match_int8(const int8_t *q_dev, const int32_t *q_norm2_dev,
+                       const int8_t *t_dev, const int32_t *t_norm2_dev,
+                       const int32_t *seg_dev, int batch, int max_nq, int max_nt,
+                       int dim, int k, int mode, double thr,
+                       const float *yq_dev, const float *yt_dev,
+                       int32_t *out_idx_dev, float *out_dist_dev, uint8_t *keep_dev,
+                       void *stream);
+
+/*
  * The two match filters on their own, for callers that already hold match lists.
  * slam_ratio_filter replaces Matcher.apply_threshold / apply_thresholds
  * (models/Matcher.py:148-160,178-184): idx, dist [n,2] int32 dev as written by

@@ -17,6 +17,8 @@ EXPORTS = (
     "slam_hamming_match",
     "slam_hamming_knn2",
     "slam_l2_match",
+    "slam_l2_pack_int8",
+    "slam_l2_match_int8",
     "slam_ratio_filter",
     "slam_row_filter",
     "slam_triangulate_dlt",
@@ -67,6 +69,10 @@ def load():
     lib.slam_hamming_knn2.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp]
     lib.slam_l2_match.restype = ci
     lib.slam_l2_match.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, vp]
+    lib.slam_l2_pack_int8.restype = ci
+    lib.slam_l2_pack_int8.argtypes = [vp, ci, ci, vp, vp, vp, vp]
+    lib.slam_l2_match_int8.restype = ci
+    lib.slam_l2_match_int8.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, vp]
     lib.slam_ratio_filter.restype = ci
     lib.slam_ratio_filter.argtypes = [vp, vp, ci, cd, vp, vp]
     lib.slam_row_filter.restype = ci

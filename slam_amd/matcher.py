@@ -84,7 +84,13 @@ class HipBFMatcher:
         if tyt is not None and tyt.numel() == 0:
             tyt = torch.zeros(1, dtype=torch.float32, device=dev)
         if q.dtype == torch.float32:
-            idx, dist, keep = ops.l2_match(q, t, seg, nq, nt, k=k, mode=mode, thr=thr, yq=tyq, yt=tyt, n_rows=nq)
+            # integer-valued descriptors (cv2's SIFT output) go to the int8 matrix cores: same result
+            q8, t8 = ops.l2_pack_int8(q), ops.l2_pack_int8(t)
+            if q8.usable() and t8.usable():
+                idx, dist, keep = ops.l2_match_int8(q8, t8, seg, nq, nt, k=k, mode=mode, thr=thr, yq=tyq, yt=tyt,
+                                                    n_rows=nq)
+            else:
+                idx, dist, keep = ops.l2_match(q, t, seg, nq, nt, k=k, mode=mode, thr=thr, yq=tyq, yt=tyt, n_rows=nq)
         else:
             idx, dist, keep = ops.hamming_match(q, t, seg, nq, nt, Dq, k=k, mode=mode, thr=thr, yq=tyq, yt=tyt,
                                                 n_rows=nq)

@@ -126,6 +126,61 @@ def l2_match(q, t, seg, max_nq, max_nt, k=2, mode=0, thr=0.0, yq=None, yt=None, 
     return idx, dist, keep
 
 
+class Int8Table:
+    """An integer-valued float descriptor table packed for the matrix-core L2 matcher:
+    desc [n, dim] int8 (value - 128), norm2 [n] int32, bad [1] int32 (entries that were not
+    integers in 0..255: the table is usable only when it is 0)."""
+
+    def __init__(self, desc, norm2, bad):
+        self.desc, self.norm2, self.bad = desc, norm2, bad
+
+    def usable(self):
+        """Synchronises: reads the counter back."""
+        return int(self.bad.item()) == 0
+
+
+def l2_pack_int8(desc):
+    """[n, 128|64] float32 -> Int8Table (slam_l2_pack_int8)."""
+    lib = _lib.load()
+    if desc.dim() != 2:
+        raise ValueError("l2_pack_int8: expected [n, dim]")
+    n, dim = desc.shape
+    dev = desc.device
+    out = torch.empty((n, dim), dtype=torch.int8, device=dev)
+    norm2 = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+    bad = torch.zeros((1,), dtype=torch.int32, device=dev)
+    st = lib.slam_l2_pack_int8(_dev(desc, torch.float32, "desc"), n, dim, ctypes.c_void_p(out.data_ptr()),
+                               ctypes.c_void_p(norm2.data_ptr()), ctypes.c_void_p(bad.data_ptr()), _stream())
+    _lib.check(st, "slam_l2_pack_int8")
+    return Int8Table(out, norm2, bad)
+
+
+def l2_match_int8(q, t, seg, max_nq, max_nt, k=2, mode=0, thr=0.0, yq=None, yt=None, n_rows=None):
+    """l2_match on packed tables (q, t: Int8Table; slam_l2_match_int8): same results as l2_match on
+    the float tables they were packed from, on the int8 matrix cores."""
+    lib = _lib.load()
+    if q.desc.shape[1] != t.desc.shape[1]:
+        raise ValueError("l2_match_int8: q and t must have equal dim")
+    batch = seg.shape[0]
+    if n_rows is None:
+        n_rows = q.desc.shape[0]
+    dev = q.desc.device
+    idx = torch.full((n_rows, 2), -1, dtype=torch.int32, device=dev)
+    dist = torch.full((n_rows, 2), FLT_MAX, dtype=torch.float32, device=dev)
+    keep = torch.zeros((n_rows,), dtype=torch.uint8, device=dev) if mode else None
+    null = ctypes.c_void_p(0)
+    st = lib.slam_l2_match_int8(
+        _dev(q.desc, torch.int8, "q"), _dev(q.norm2, torch.int32, "q.norm2"), _dev(t.desc, torch.int8, "t"),
+        _dev(t.norm2, torch.int32, "t.norm2"), _dev(seg, torch.int32, "seg"), batch, int(max_nq), int(max_nt),
+        q.desc.shape[1], int(k), int(mode), float(thr),
+        _dev(yq, torch.float32, "yq") if yq is not None else null,
+        _dev(yt, torch.float32, "yt") if yt is not None else null,
+        ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(dist.data_ptr()),
+        ctypes.c_void_p(keep.data_ptr()) if keep is not None else null, _stream())
+    _lib.check(st, "slam_l2_match_int8")
+    return idx, dist, keep
+
+
 def hamming_knn2(q, t, seg, max_nq, max_nt, desc_bytes, k=2, n_rows=None):
     """Unfiltered batched Hamming k-NN (slam_hamming_knn2)."""
     lib = _lib.load()

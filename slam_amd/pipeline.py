@@ -41,6 +41,13 @@ class FrameTables:
         self.desc_bytes = int(desc_bytes)
         self.n_frames = len(self.offL) - 1
         self.device = descL.device
+        # Float descriptors that hold integers 0..255 (cv2's SIFT output) are also kept packed for
+        # the int8 matrix-core L2 matcher (ops.Int8Table); None: use the fp32 matcher.
+        self.i8L = self.i8R = None
+        if descL.dtype == torch.float32:
+            i8L, i8R = ops.l2_pack_int8(descL), ops.l2_pack_int8(descR)
+            if i8L.usable() and i8R.usable():
+                self.i8L, self.i8R = i8L, i8R
 
     @classmethod
     def from_frames(cls, frames, device):
@@ -167,8 +174,13 @@ class FrontEnd:
         return ws
 
     # -- the five launches ---------------------------------------------------
-    def _match(self, q, t, seg, batch, max_nq, max_nt, desc_bytes, k, mode, thr, yq, yt, idx, dist, keep, stream, what):
-        if q.dtype == torch.float32:      # float descriptors: L2 norm, as cv2.BFMatcher() on SIFT
+    def _match(self, q, t, seg, batch, max_nq, max_nt, desc_bytes, k, mode, thr, yq, yt, idx, dist, keep, stream, what,
+               q8=None, t8=None):
+        if q8 is not None and t8 is not None:   # integer-valued float descriptors: L2 on the int8 matrix cores
+            st = self.lib.slam_l2_match_int8(_p(q8.desc), _p(q8.norm2), _p(t8.desc), _p(t8.norm2), _p(seg), batch,
+                                             max_nq, max_nt, q8.desc.shape[1], k, mode, thr, _p(yq), _p(yt), _p(idx),
+                                             _p(dist), _p(keep), stream)
+        elif q.dtype == torch.float32:    # float descriptors: L2 norm, as cv2.BFMatcher() on SIFT
             st = self.lib.slam_l2_match(_p(q), _p(t), _p(seg), batch, max_nq, max_nt, q.shape[1], k, mode, thr,
                                         _p(yq), _p(yt), _p(idx), _p(dist), _p(keep), stream)
         else:
@@ -179,7 +191,8 @@ class FrontEnd:
     def stereo_match(self, ws, stream):
         tb = ws.tb
         return self._match(tb.descL, tb.descR, ws.seg_s, ws.F, ws.max_nL, ws.max_nR, tb.desc_bytes, 1, 2,
-                           self.row_thresh, tb.yL, tb.yR, ws.s_idx, ws.s_dist, ws.s_keep, stream, "match(stereo)")
+                           self.row_thresh, tb.yL, tb.yR, ws.s_idx, ws.s_dist, ws.s_keep, stream, "match(stereo)",
+                           q8=tb.i8L, t8=tb.i8R)
 
     def triangulate(self, ws, stream):
         tb = ws.tb
@@ -191,7 +204,8 @@ class FrontEnd:
     def temporal_match(self, ws, stream):
         tb = ws.tb
         return self._match(tb.descL, tb.descL, ws.seg_t, ws.P, ws.max_nL, ws.max_nL, tb.desc_bytes, 2, 1,
-                           self.ratio_thresh, None, None, ws.t_idx, ws.t_dist, ws.t_keep, stream, "match(temporal)")
+                           self.ratio_thresh, None, None, ws.t_idx, ws.t_dist, ws.t_keep, stream, "match(temporal)",
+                           q8=tb.i8L, t8=tb.i8L)
 
     def join(self, ws, stream):
         tb, c = ws.tb, ws.cons
