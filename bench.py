@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 INT_VALU_PEAK_TOPS = 78.6   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz simple int32 ops (nominal)
 INT_VALU_MEASURED_MIX_TOPS = 50.3  # tools/valu_peak.hip on the box: v_xor_b32 + v_bcnt_u32_b32 (bcnt is half rate)
 INT8_MFMA_PEAK_TOPS = 5000.0       # dense int8 MFMA = 2 x the 2.5 PFLOP/s bf16 peak
+FP4_MFMA_PEAK_TOPS = 10000.0       # dense fp4/fp6 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4) = 4 x bf16
 HBM_PEAK_GBS = 8000.0
 FP64_VALU_PEAK_TF = 78.6    # 256 CU x 64 fp64 FMA lanes/clk x 2 flop x 2.4 GHz
 FP32_VALU_PEAK_TF = 157.3   # plain (unpacked) fp32 FMA issues at twice the fp64 rate
@@ -327,7 +328,9 @@ def main():
     pairs_temporal = float((nL[:-1] * nL[1:]).sum())
     match_pairs = pairs_stereo + pairs_temporal
     match_ms = stage_ms["stereo_match"] + stage_ms["temporal_match"]
-    valu_impl = os.environ.get("SLAM_KNN_IMPL", "mfma").startswith("v")
+    knn_impl = os.environ.get("SLAM_KNN_IMPL", "") or "fp4"
+    valu_impl = knn_impl.startswith("v")
+    fp4_impl = knn_impl.startswith("f")
     n_cons = ws.cons.count.cpu().numpy()[:P].astype(np.float64)
     n_tri = float(ws.s_keep.sum().item())
     tri_bytes = 41.0 * n_tri
@@ -345,14 +348,16 @@ def main():
     # BASELINE's "INT roofline") and as int8 MACs on the matrix cores (8*D bit products per pair)
     valu_tops = 2.0 * words * match_pairs / (match_ms * 1e-3) / 1e12
     mfma_tops = 2.0 * 8 * tb.desc_bytes * match_pairs / (match_ms * 1e-3) / 1e12
-    knn_name = "hamming_knn_kernel" if valu_impl else "hamming_mfma_kernel"
+    knn_name = "hamming_knn_kernel" if valu_impl else ("hamming_fp4_kernel" if fp4_impl else "hamming_mfma_kernel")
+    mfma_peak = FP4_MFMA_PEAK_TOPS if fp4_impl else INT8_MFMA_PEAK_TOPS
+    mfma_unit = "TOP/s (fp4 matrix cores: one e2m1 slot per descriptor bit)" if fp4_impl else "TOP/s (int8)"
     match_roof = {
         "kernel": f"{knn_name} (2 launches per step: stereo k=1 + temporal k=2)",
         "bound": "valu" if valu_impl else "mfma",
         "achieved": valu_tops if valu_impl else mfma_tops,
-        "peak": INT_VALU_PEAK_TOPS if valu_impl else INT8_MFMA_PEAK_TOPS,
-        "unit": "Tint32-op/s" if valu_impl else "TOP/s (int8)",
-        "frac": (valu_tops / INT_VALU_PEAK_TOPS) if valu_impl else (mfma_tops / INT8_MFMA_PEAK_TOPS),
+        "peak": INT_VALU_PEAK_TOPS if valu_impl else mfma_peak,
+        "unit": "Tint32-op/s" if valu_impl else mfma_unit,
+        "frac": (valu_tops / INT_VALU_PEAK_TOPS) if valu_impl else (mfma_tops / mfma_peak),
         "traffic": traffic.get(f"{knn_name}_bytes_per_launch"),
         "avg_launch_ms": match_ms / 2.0,
         "pairs_per_s": match_pairs / (match_ms * 1e-3),
@@ -361,7 +366,7 @@ def main():
                                 "measured_xor_bcnt_peak": INT_VALU_MEASURED_MIX_TOPS,
                                 "algorithmic": f"{2 * words} int32 ops per descriptor pair"},
         "algorithmic": f"{match_pairs:.4g} descriptor pairs per step x "
-                       + (f"{2 * words} int32 ops" if valu_impl else f"{2 * 8 * tb.desc_bytes} int8 ops (8*D MACs)"),
+                       + (f"{2 * words} int32 ops" if valu_impl else f"{2 * 8 * tb.desc_bytes} matrix-core ops (8*D MACs)"),
     }
     score_tf = 72.0 * score_evals / (stage_ms["score"] * 1e-3) / 1e12
     f64_only = os.environ.get("SLAM_SCORE_IMPL", "mixed").startswith("f6")
@@ -402,7 +407,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": ("u32 popcount" if valu_impl else "int8 MFMA (exact Hamming)") + " matching + f64 triangulation + f32-filtered f64 scoring",
+        "dtype": ("u32 popcount" if valu_impl else ("fp4 MFMA (exact Hamming)" if fp4_impl else "int8 MFMA (exact Hamming)")) + " matching + f64 triangulation + f32-filtered f64 scoring",
         "data": "synthetic",
         "config": {"workload": "configs[1]: consecutive frame pairs, 4-way match + PnP-RANSAC scoring of a fixed "
                                "seeded hypothesis set", "pairs_per_gpu_per_step": P, "keypoints_per_image": N,

@@ -279,11 +279,13 @@ extern "C" int slam_hamming_match(const uint8_t *q, const uint8_t *t, const int3
     a.out_dist = out_dist;
     a.keep = keep;
     hipStream_t s = (hipStream_t)stream;
-    // Two implementations with identical results: the matrix-core kernel (default) and the
-    // VALU popcount kernel (SLAM_KNN_IMPL=valu), kept for comparison runs.
+    // Three implementations with identical results: the fp4 matrix-core kernel (default), the
+    // int8 matrix-core kernel (SLAM_KNN_IMPL=mfma) and the VALU popcount kernel
+    // (SLAM_KNN_IMPL=valu), the latter two kept for comparison runs.
     const char *impl = getenv("SLAM_KNN_IMPL");
-    const bool use_valu = impl && impl[0] == 'v';
-    if (!use_valu)
+    if (!impl || impl[0] == 'f' || impl[0] == '\0')
+        return launch_knn_fp4(a, batch, max_nq, stride_bytes, s);
+    if (impl[0] != 'v')
         return launch_knn_mfma(a, batch, max_nq, stride_bytes, s);
     if (stride_bytes == 64)
         return dispatch_q<16>(a, batch, max_nq, s);

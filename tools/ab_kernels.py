@@ -36,9 +36,9 @@ def timed(fn, reps=3):
     return e0.elapsed_time(e1) / reps
 
 
-res = {"score": {"mixed": [], "f64": [], "bf16": []}, "knn": {"mfma": [], "valu": []}}
+res = {"score": {"mixed": [], "f64": [], "bf16": []}, "knn": {"mfma": [], "valu": [], "fp4": []}}
 for rnd in range(8):
-    for impl, simpl in (("mfma", "mixed"), ("valu", "f64"), ("mfma", "bf16")):
+    for impl, simpl in (("mfma", "mixed"), ("valu", "f64"), ("fp4", "bf16")):
         os.environ["SLAM_SCORE_IMPL"] = simpl
         res["score"][simpl].append(timed(lambda: fe.score(ws, Rt, stream)))
         os.environ["SLAM_KNN_IMPL"] = impl

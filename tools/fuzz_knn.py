@@ -42,15 +42,17 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     qd = ops.pack_descriptors(torch.from_numpy(q).to(dev), D, stride) if q.shape[0] else torch.zeros((0, stride), dtype=torch.uint8, device=dev)
     td = ops.pack_descriptors(torch.from_numpy(t).to(dev), D, stride) if t.shape[0] else torch.zeros((0, stride), dtype=torch.uint8, device=dev)
     out = {}
-    for impl in ("mfma", "valu"):
+    for impl in ("mfma", "valu", "fp4"):
         os.environ["SLAM_KNN_IMPL"] = impl
         idx, dist, keep = ops.hamming_match(qd, td, torch.from_numpy(seg).to(dev), max(nq), max(nt), D, k=2, mode=mode,
                                             thr=thr, yq=yq if mode == 2 else None, yt=yt if mode == 2 else None,
                                             n_rows=int(q.shape[0]))
         torch.cuda.synchronize()
         out[impl] = (idx.cpu().numpy(), dist.cpu().numpy(), None if keep is None else keep.cpu().numpy())
-    a, b = out["mfma"], out["valu"]
-    d = int((a[0] != b[0]).sum() + (a[1] != b[1]).sum() + (0 if a[2] is None else (a[2] != b[2]).sum()))
+    b = out["valu"]
+    d = 0
+    for a in (out["mfma"], out["fp4"]):
+        d += int((a[0] != b[0]).sum() + (a[1] != b[1]).sum() + (0 if a[2] is None else (a[2] != b[2]).sum()))
     pairs += int(sum(x * y for x, y in zip(nq, nt)))
     if d:
         bad += d

@@ -13,7 +13,7 @@ for p in ("p1","p2"):
         agg=collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             n=r["Kernel_Name"]
-            if "hamming_mfma" in n or "score_mixed" in n:
+            if "hamming_mfma" in n or "hamming_fp4" in n or "score_mixed" in n:
                 agg[(("knn" if "hamming" in n else "score"),r["Counter_Name"])].append(float(r["Counter_Value"]))
         for k,v in sorted(agg.items()):
             print(k[0],k[1],len(v),"%.4g"%(sum(v)/len(v)))
