@@ -74,8 +74,9 @@ __device__ __forceinline__ i32x4 expand_query(uint32_t w)
 
 __device__ __forceinline__ i32x8 widen(i32x4 v) { return i32x8{v.x, v.y, v.z, v.w, 0, 0, 0, 0}; }
 
-// KM = MFMAs (64 bits each) per row: 8 for 64-byte rows, 4 for 32-byte; QT = query tiles per wave
-template <int KM, int QT>
+// KM = MFMAs (64 bits each) per row: 8 for 64-byte rows, 4 for 32-byte; QT = query tiles per wave;
+// K2 = keep the second neighbour too (k = 2); k = 1 saves the median per accumulator
+template <int KM, int QT, bool K2>
 __global__ void __launch_bounds__(BLOCK, 3) hamming_fp4_kernel(const KnnArgs a)
 {
     constexpr int C = KM / 2;           // 16-byte chunks per packed row
@@ -156,7 +157,8 @@ __global__ void __launch_bounds__(BLOCK, 3) hamming_fp4_kernel(const KnnArgs a)
     float inf = __builtin_inff();
     asm volatile("" : "+v"(inf));
     auto top2 = [&](int t, float v) __attribute__((always_inline)) {
-        b2[t] = med3f(b1[t], b2[t], v);
+        if (K2)
+            b2[t] = med3f(b1[t], b2[t], v);
         b1[t] = med3f(b1[t], v, inf);
     };
     // b1/b2 hold key + (chunk-local first row of the tile merged last); moving on by one tile:
@@ -274,7 +276,7 @@ __global__ void __launch_bounds__(BLOCK, 3) hamming_fp4_kernel(const KnnArgs a)
     }
 }
 
-template <int KM, int QT>
+template <int KM, int QT, bool K2>
 int launch(const KnnArgs &a, int batch, int max_nq, hipStream_t s)
 {
     KnnArgs args = a;
@@ -282,7 +284,7 @@ int launch(const KnnArgs &a, int batch, int max_nq, hipStream_t s)
     const long long blocks = (long long)batch * args.tiles_per_item;
     if (blocks > 0x7FFFFFFFLL)
         return fail(SLAM_ERR_BAD_ARG, "slam_hamming_match: grid too large (%lld blocks)", blocks);
-    hipLaunchKernelGGL((hamming_fp4_kernel<KM, QT>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, args);
+    hipLaunchKernelGGL((hamming_fp4_kernel<KM, QT, K2>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, args);
     return check_launch("slam_hamming_match(fp4)");
 }
 
@@ -292,9 +294,14 @@ int launch_knn_fp4(const KnnArgs &a, int batch, int max_nq, int stride_bytes, hi
 {
     auto blocks = [&](int qt) { return (long long)batch * ((max_nq + 128 * qt - 1) / (128 * qt)); };
     const bool wide = blocks(2) >= 512;
-    if (stride_bytes == 64)
-        return wide ? launch<8, 2>(a, batch, max_nq, s) : launch<8, 1>(a, batch, max_nq, s);
-    return wide ? launch<4, 2>(a, batch, max_nq, s) : launch<4, 1>(a, batch, max_nq, s);
+    if (stride_bytes == 64) {
+        if (a.k >= 2)
+            return wide ? launch<8, 2, true>(a, batch, max_nq, s) : launch<8, 1, true>(a, batch, max_nq, s);
+        return wide ? launch<8, 2, false>(a, batch, max_nq, s) : launch<8, 1, false>(a, batch, max_nq, s);
+    }
+    if (a.k >= 2)
+        return wide ? launch<4, 2, true>(a, batch, max_nq, s) : launch<4, 1, true>(a, batch, max_nq, s);
+    return wide ? launch<4, 2, false>(a, batch, max_nq, s) : launch<4, 1, false>(a, batch, max_nq, s);
 }
 
 }  // namespace slam
