@@ -19,8 +19,9 @@
 // buffered, row stride 32 KM + 16 bytes: conflict-free ds_read_b128 A fragments); a tile's MFMAs
 // are followed by its top-2 update, three waves per SIMD cover each other's waits; one barrier
 // per super-tile.  Keys are exact small integers held
-// in fp32 (|key| < 2^20), the running top two per lane are v_max_f32 + v_med3_f32; every 1024
-// rows they are folded into the (distance << 22 | index) keys shared with the other kernels.
+// in fp32 (|key| < 2^20, biased to be positive), the running top two per lane take 1.25
+// instructions per accumulator (v_max3_i32 on the bit patterns, v_med3_f32); every 1024 rows
+// they are folded into the (distance << 22 | index) keys shared with the other kernels.
 #include "knn_common.h"
 
 namespace slam {
@@ -35,19 +36,25 @@ constexpr int TS = 64;            // train rows per super-tile
 constexpr int CHUNK = 1024;       // train rows per key chunk
 constexpr int JBITS = 10;
 
-// "No candidate": real keys lie above -2^20; the sentinel may have a row index subtracted from
-// it like any other value and stays below -2^29.
-constexpr float SENT = -1073741824.0f;
-__device__ __forceinline__ bool is_candidate(float v) { return v > -536870912.0f; }
+// Every value is kept positive -- BIAS + key, with |key| < 2^20 -- so that the fp32 bit patterns
+// order like the values and integer maxima can be taken on them.  "No candidate" is 0: it may be
+// moved along with the running winners (+32 per tile, at most 32 tiles per chunk) and stays
+// far below every real value.
+constexpr float BIAS = 4194304.0f;         // 2^22
+constexpr float SENT = 0.0f;
+__device__ __forceinline__ bool is_candidate(float v) { return v > 2097152.0f; }
 
 constexpr int SCALE_ONE = 0x7F7F7F7F;      // E8M0 block scales, 2^(e - 127): 1
 constexpr int SCALE_1024 = 0x89898989;     //                                 1024
 
-// Median and maximum both go through the med3 builtin (max(a, b) = med3(a, b, +inf), the infinity
-// held in a register the compiler cannot see through): the compiler then sees ordinary VALU reads
-// of the MFMA results and inserts the wait states they need -- it pads nothing around inline asm --
-// and adds no canonicalising copy, as it does for fmaxf, of values that are exact integers anyway.
+// The median goes through the builtin and the maxima are plain integer max() on the bit patterns
+// (v_max3_i32): the compiler then sees ordinary VALU reads of the MFMA results and inserts the
+// wait states they need -- it pads nothing around inline asm.
 __device__ __forceinline__ float med3f(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+__device__ __forceinline__ float max3_bits(float a, float b, float c)
+{
+    return __int_as_float(max(max(__float_as_int(a), __float_as_int(b)), __float_as_int(c)));
+}
 
 // Train side: 32 bits -> 32 fp4 slots (one operand register quad).
 __device__ __forceinline__ i32x4 expand_train(uint32_t w)
@@ -154,12 +161,23 @@ __global__ void __launch_bounds__(BLOCK, 3) hamming_fp4_kernel(const KnnArgs a)
     };
     // offset of accumulator register r's train row inside a 32-row tile, for this lane
     auto row_off = [&](int r) __attribute__((always_inline)) { return (r & 3) + 8 * (r >> 2) + 4 * half; };
-    float inf = __builtin_inff();
-    asm volatile("" : "+v"(inf));
-    auto top2 = [&](int t, float v) __attribute__((always_inline)) {
-        if (K2)
-            b2[t] = med3f(b1[t], b2[t], v);
-        b1[t] = med3f(b1[t], v, inf);
+    // Running top two of query tile t against the 16 accumulators v[0..15] of a tile, two at a
+    // time: with b1 >= b2, the second largest of {b1, b2, x, y} is max(b2, med3(b1, x, y)); the
+    // medians of four such steps are folded into b2 by two three-way maxima.  1.25 instructions
+    // per accumulator (0.5 when only the nearest neighbour is wanted).
+    auto top2_tile = [&](int t, const float (&v)[16]) __attribute__((always_inline)) {
+        float m[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (K2)
+                m[i] = med3f(b1[t], v[2 * i], v[2 * i + 1]);
+            b1[t] = max3_bits(b1[t], v[2 * i], v[2 * i + 1]);
+        }
+        if (K2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                b2[t] = max3_bits(b2[t], m[2 * i], m[2 * i + 1]);
+        }
     };
     // b1/b2 hold key + (chunk-local first row of the tile merged last); moving on by one tile:
     auto rebase = [&]() __attribute__((always_inline)) {
@@ -171,10 +189,10 @@ __global__ void __launch_bounds__(BLOCK, 3) hamming_fp4_kernel(const KnnArgs a)
     };
 
     const int n_st = (tn + TS - 1) / TS;
-    f32x16 cneg;               // -(row offset of accumulator register r inside a tile), without the lane's 4 * half
+    f32x16 cneg;               // BIAS - (row offset of accumulator register r inside a tile), without the lane's 4 * half
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-        cneg[r] = -(float)((r & 3) + 8 * (r >> 2));
+        cneg[r] = BIAS - (float)((r & 3) + 8 * (r >> 2));
 
     if (n_st > 0) {
         const uint4 r0 = load_raw(0);
@@ -206,19 +224,23 @@ __global__ void __launch_bounds__(BLOCK, 3) hamming_fp4_kernel(const KnnArgs a)
             expand_store(nbuf, wb, eb);
         }
         rebase();
-        if (row0 + 32 <= tn) {
+        if (row0 + 32 <= tn) {              // the common case: no select instructions
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
+            for (int t = 0; t < QT; ++t) {
+                float v[16];
 #pragma unroll
-                for (int t = 0; t < QT; ++t)
-                    top2(t, acc[t][r]);
+                for (int r = 0; r < 16; ++r)
+                    v[r] = acc[t][r];
+                top2_tile(t, v);
+            }
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const bool in = row0 + row_off(r) < tn;
+            for (int t = 0; t < QT; ++t) {
+                float v[16];
 #pragma unroll
-                for (int t = 0; t < QT; ++t)
-                    top2(t, in ? acc[t][r] : SENT);
+                for (int r = 0; r < 16; ++r)
+                    v[r] = row0 + row_off(r) < tn ? acc[t][r] : SENT;
+                top2_tile(t, v);
             }
         }
     };
@@ -250,7 +272,7 @@ __global__ void __launch_bounds__(BLOCK, 3) hamming_fp4_kernel(const KnnArgs a)
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     if (is_candidate(v[e])) {
-                        const int key = -(int)(v[e] - base);         // 1024 * (ham - pop(q)) + j', j' in [0, 1024)
+                        const int key = -(int)(v[e] - BIAS - base);  // 1024 * (ham - pop(q)) + j', j' in [0, 1024)
                         const int ham = (key >> JBITS) + popq[t];    // arithmetic shift floors
                         const int j = (key & (CHUNK - 1)) + 4 * half;
                         const uint32_t gk = ((uint32_t)ham << KEY_SHIFT) | (uint32_t)(chunk0 + j);
