@@ -20,7 +20,8 @@
 //     key = (a'.b' << 9) + c_j = 256 (2 a'.b' - |b'_j|^2) + (255 - j mod 256)
 //
 // i.e. smallest distance first, lowest index first inside a 256-row chunk: one
-// v_lshl_add_u32 per accumulator, then v_max_i32 + v_med3_i32 for the running top two.  Every 256
+// v_lshl_add_u32 per accumulator, then 1.25 instructions per accumulator for the running top two
+// (v_max3_i32 and one v_med3_i32 per two keys).  Every 256
 // rows the two winners are folded into (distance, index) pairs.  |key| < 1.62e9 fits an int.
 #include "common.h"
 
@@ -214,14 +215,22 @@ __global__ void __launch_bounds__(256, 2) l2_mfma_kernel(const L2iArgs a)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             cc[g] = *reinterpret_cast<const i32x4 *>(cbase + 8 * g + 4 * half);
+        // running top two, two keys x, y at a time: with b1 >= b2 the second largest of
+        // {b1, b2, x, y} is max(b2, med3(b1, x, y)); the medians are folded into b2 pairwise
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
+            int m[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = (int)(((uint32_t)acc[t][r] << 9) + (uint32_t)cc[r >> 2][r & 3]);
-                b2[t] = med3i(b1[t], b2[t], key);
-                b1[t] = max(b1[t], key);
+            for (int i = 0; i < 8; ++i) {
+                const int r = 2 * i;
+                const int x = (int)(((uint32_t)acc[t][r] << 9) + (uint32_t)cc[r >> 2][r & 3]);
+                const int y = (int)(((uint32_t)acc[t][r + 1] << 9) + (uint32_t)cc[(r + 1) >> 2][(r + 1) & 3]);
+                m[i] = med3i(b1[t], x, y);
+                b1[t] = max(max(b1[t], x), y);
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                b2[t] = max(max(b2[t], m[2 * i]), m[2 * i + 1]);
         }
     };
 
