@@ -345,7 +345,7 @@ def main():
             traffic = {}
 
     # matching: descriptor pairs; as int32 VALU work (1 xor + 1 popcount-accumulate per 32-bit word,
-    # BASELINE's "INT roofline") and as int8 MACs on the matrix cores (8*D bit products per pair)
+    # BASELINE's "INT roofline") and as multiply-accumulates on the matrix cores (8*D bit products per pair)
     valu_tops = 2.0 * words * match_pairs / (match_ms * 1e-3) / 1e12
     mfma_tops = 2.0 * 8 * tb.desc_bytes * match_pairs / (match_ms * 1e-3) / 1e12
     knn_name = "hamming_knn_kernel" if valu_impl else ("hamming_fp4_kernel" if fp4_impl else "hamming_mfma_kernel")
