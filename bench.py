@@ -90,6 +90,12 @@ def cpu_baseline(seq, Rt_host, n_pairs, threads):
 
 def main():
     a = parse()
+    # stdout carries exactly one line, the JSON result: libraries that print to file descriptor 1
+    # (RCCL writes a version banner there when a communicator is created) are sent to stderr, and
+    # the result line goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -429,7 +435,8 @@ def main():
         out["cpu_baseline"] = {"value": v, "unit": "frame-pairs/s", "cores": threads, "kind": "port",
                                "sample": f"first {n_cpu} frame pairs of the same batch ({N} kp, {H} hypotheses), "
                                          f"C oracle with OpenMP over queries/points/hypotheses, {secs:.1f} s"}
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(result_fd, (json.dumps(out) + "\n").encode())
     if multi:
         dist.destroy_process_group()
 
