@@ -123,32 +123,83 @@ struct MatchedArgs {
     int32_t *stereo_map;
 };
 
+// A block takes DLT_TILE keypoints of one frame.  Only the kept matches are triangulated (about
+// 60 % of the keypoints): their local indices are compacted into LDS first, so that the
+// wavefronts running the Jacobi iteration are full.
+constexpr int DLT_TILE = 512;
+
 __global__ void __launch_bounds__(256) dlt_matched_kernel(const Mat34 P, const Mat34 Q, const MatchedArgs a)
 {
+    __shared__ int list[DLT_TILE];
+    __shared__ int wave_base[DLT_TILE / 64 + 1];
     const int item = blockIdx.x / a.tiles_per_item;
     const int tile = blockIdx.x - item * a.tiles_per_item;
     const int32_t *seg = a.seg + SLAM_SEG_STRIDE * item;
     const int qs = seg[0], qn = seg[1], ts = seg[2], os = seg[4];
-    const int i = tile * 256 + threadIdx.x;
-    if (i >= qn)
+    const int i0 = tile * DLT_TILE;
+    if (i0 >= qn)
         return;
-    const size_t g = (size_t)os + i;
-    int j = -1;
-    if (a.keep[g])
-        j = a.idx[2 * g];
-    double x = __builtin_nan(""), y = x, z = x;
-    bool ok = false;
-    if (j >= 0) {
-        const float fx1 = a.xq[qs + i], fx2 = a.xt[ts + j];
-        dlt_point(P, Q, (double)fx1, (double)a.yq[qs + i], (double)fx2, (double)a.yt[ts + j], x, y, z);
-        ok = !(z <= 0.0 || fx1 < fx2);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // pass 1: results of the keypoints without a kept match, and the per-wavefront counts of the others
+    int jj[DLT_TILE / 256];
+    unsigned long long mask[DLT_TILE / 256];
+#pragma unroll
+    for (int e = 0; e < DLT_TILE / 256; ++e) {
+        const int i = i0 + e * 256 + tid;
+        int j = -1;
+        if (i < qn) {
+            const size_t g = (size_t)os + i;
+            if (a.keep[g])
+                j = a.idx[2 * g];
+            if (j < 0) {
+                const double nan = __builtin_nan("");
+                a.X[g] = nan;
+                a.Y[g] = nan;
+                a.Z[g] = nan;
+                a.valid[g] = 0;
+            }
+            if (a.stereo_map)
+                a.stereo_map[g] = j;
+        }
+        jj[e] = j;
+        mask[e] = __ballot(j >= 0);
+        if (lane == 0)
+            wave_base[e * 4 + wave] = __popcll(mask[e]);
     }
-    a.X[g] = x;
-    a.Y[g] = y;
-    a.Z[g] = z;
-    a.valid[g] = ok;
-    if (a.stereo_map)
-        a.stereo_map[g] = j;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+#pragma unroll
+        for (int w = 0; w < DLT_TILE / 64; ++w) {
+            const int c = wave_base[w];
+            wave_base[w] = run;
+            run += c;
+        }
+        wave_base[DLT_TILE / 64] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < DLT_TILE / 256; ++e) {
+        if (jj[e] >= 0) {
+            const int pos = wave_base[e * 4 + wave] + __popcll(mask[e] & ((1ull << lane) - 1ull));
+            list[pos] = e * 256 + tid;
+        }
+    }
+    __syncthreads();
+    // pass 2: the kept matches, densely
+    const int count = wave_base[DLT_TILE / 64];
+    for (int k = tid; k < count; k += 256) {
+        const int i = i0 + list[k];
+        const size_t g = (size_t)os + i;
+        const int j = a.idx[2 * g];
+        const float fx1 = a.xq[qs + i], fx2 = a.xt[ts + j];
+        double x, y, z;
+        dlt_point(P, Q, (double)fx1, (double)a.yq[qs + i], (double)fx2, (double)a.yt[ts + j], x, y, z);
+        a.X[g] = x;
+        a.Y[g] = y;
+        a.Z[g] = z;
+        a.valid[g] = !(z <= 0.0 || fx1 < fx2);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -265,7 +316,7 @@ extern "C" int slam_triangulate_matched(const double *P, const double *Q, const 
     a.xt = xt;
     a.yt = yt;
     a.seg = seg;
-    a.tiles_per_item = (max_nq + 255) / 256;
+    a.tiles_per_item = (max_nq + DLT_TILE - 1) / DLT_TILE;
     a.idx = idx;
     a.keep = keep;
     a.X = X;
