@@ -112,6 +112,7 @@ __global__ void __launch_bounds__(BLOCK, 3) hamming_fp4_kernel(const KnnArgs a)
     // ---- B operands: this wave's queries; MFMA m takes word 2m + half of the row ------------
     i32x4 bq[QT][KM];
     int popq[QT];
+    const uint32_t hmask = 0u - (uint32_t)half;     // all ones in the upper lane half
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int row = q0 + (wave * QT + t) * 32 + col;
@@ -127,7 +128,7 @@ __global__ void __launch_bounds__(BLOCK, 3) hamming_fp4_kernel(const KnnArgs a)
                 popq[t] += __popc(w4[e] & word_mask(4 * c + e, a.desc_bytes));
 #pragma unroll
             for (int p = 0; p < 2; ++p)        // words 4c + 2p (half 0) and 4c + 2p + 1 (half 1) -> MFMA 2c + p
-                bq[t][2 * c + p] = expand_query(half ? w4[2 * p + 1] : w4[2 * p]);
+                bq[t][2 * c + p] = expand_query((w4[2 * p] & ~hmask) | (w4[2 * p + 1] & hmask));
         }
     }
 
