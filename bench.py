@@ -36,7 +36,7 @@ FP64_VALU_PEAK_TF = 78.6    # 256 CU x 64 fp64 FMA lanes/clk x 2 flop x 2.4 GHz
 FP32_VALU_PEAK_TF = 157.3   # plain (unpacked) fp32 FMA issues at twice the fp64 rate
 VALU_ISSUE_PEAK_TOPS = 78.6        # full-rate VALU lane-instructions/s (nominal)
 VALU_FMA32_MEASURED_TOPS = 58.9    # tools/fp32pk_peak.hip on the box: sustained v_fma_f32
-SCORE_MIXED_VALU_PER_EVAL = 27     # VALU instructions per evaluation in score_mixed_kernel's loop (ISA count)
+SCORE_MIXED_VALU_PER_EVAL = 26     # VALU instructions per evaluation in score_mixed_kernel's loop (ISA count)
 
 
 def parse():

@@ -663,7 +663,7 @@ __global__ void __launch_bounds__(256) score_mixed_kernel(const ScoreArgs a)
 // 4-term dot products of a hypothesis row with (X, Y, Z, 1).  With every fp32 factor split
 // exactly into three bf16 pieces, a*b is the sum of the nine piece products, each exact in
 // fp32, so one output is a 30-term bf16 dot product: two v_mfma_f32_32x32x16_bf16 per output
-// for a tile of 32 hypotheses x 32 points.  That moves 10 of the 27 VALU instructions of an
+// for a tile of 32 hypotheses x 32 points.  That moves 10 of the 26 VALU instructions of an
 // evaluation to the matrix cores; the rest of the fp32 filter (16 instructions per evaluation)
 // runs on the VALU over the accumulator tile, lane = point, register = hypothesis.
 //
