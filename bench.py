@@ -434,7 +434,13 @@ def main():
         v, secs = cpu_baseline(seq, Rt_host, n_cpu, threads)
         out["cpu_baseline"] = {"value": v, "unit": "frame-pairs/s", "cores": threads, "kind": "port",
                                "sample": f"first {n_cpu} frame pairs of the same batch ({N} kp, {H} hypotheses), "
-                                         f"C oracle with OpenMP over queries/points/hypotheses, {secs:.1f} s"}
+                                         f"C oracle with OpenMP over queries/points/hypotheses, {secs:.1f} s",
+                               "host_cpu_count": os.cpu_count()}
+        # the same oracle on one thread, on a sample an eighth the size
+        n_one = max(1, n_cpu // 8)
+        v1, secs1 = cpu_baseline(seq, Rt_host, n_one, 1)
+        out["cpu_baseline"]["single_thread"] = {"value": v1, "unit": "frame-pairs/s", "cores": 1,
+                                                "sample": f"first {n_one} frame pairs, {secs1:.1f} s"}
     sys.stdout.flush()
     os.write(result_fd, (json.dumps(out) + "\n").encode())
     if multi:
