@@ -36,6 +36,7 @@ FP64_VALU_PEAK_TF = 78.6    # 256 CU x 64 fp64 FMA lanes/clk x 2 flop x 2.4 GHz
 FP32_VALU_PEAK_TF = 157.3   # plain (unpacked) fp32 FMA issues at twice the fp64 rate
 VALU_ISSUE_PEAK_TOPS = 78.6        # full-rate VALU lane-instructions/s (nominal)
 VALU_FMA32_MEASURED_TOPS = 58.9    # tools/fp32pk_peak.hip on the box: sustained v_fma_f32
+SCORE_MIX_MEASURED_TOPS = 56.7     # tools/score_mix_peak.hip: the kernel's 26-instruction stream alone
 SCORE_MIXED_VALU_PER_EVAL = 26     # VALU instructions per evaluation in score_mixed_kernel's loop (ISA count)
 
 
@@ -395,7 +396,8 @@ def main():
         score_roof["valu_issue"] = {"instructions_per_evaluation": SCORE_MIXED_VALU_PER_EVAL, "achieved": issue,
                                     "peak": VALU_ISSUE_PEAK_TOPS, "unit": "T lane-instr/s",
                                     "frac": issue / VALU_ISSUE_PEAK_TOPS,
-                                    "measured_v_fma_f32_peak": VALU_FMA32_MEASURED_TOPS}
+                                    "measured_v_fma_f32_peak": VALU_FMA32_MEASURED_TOPS,
+                                    "measured_rate_of_this_instruction_mix": SCORE_MIX_MEASURED_TOPS}
     tri_gbs = tri_bytes / (stage_ms["triangulate"] * 1e-3) / 1e9
     tri_roof = {"kernel": "dlt_matched_kernel", "bound": "hbm", "achieved": tri_gbs, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": tri_gbs / HBM_PEAK_GBS, "traffic": traffic.get("dlt_matched_kernel_bytes_per_launch"),
