@@ -43,8 +43,8 @@ SCORE_MIXED_VALU_PER_EVAL = 26     # VALU instructions per evaluation in score_m
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--pairs", type=int, default=511,
                     help="frame pairs per GPU per step (512 frames: 4096 matcher workgroups = 8 full waves of the 512 "
                          "resident ones; larger batches amortise launch tails, 127 / 255 / 1023 work as well)")
