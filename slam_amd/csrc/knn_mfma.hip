@@ -209,6 +209,12 @@ __global__ void __launch_bounds__(BLOCK, 2) hamming_mfma_kernel(const KnnArgs a)
                           __attribute__((always_inline)) {
         const uint8_t *arow = abase + col * ROW + 16 * half;
         i32x4 af = *reinterpret_cast<const i32x4 *>(arow);
+        // `pend` was written by the MFMAs of the previous phase and is read below by inline asm
+        // (v_med3_i32), around which the compiler inserts no wait states: spend the ones an MFMA
+        // result needs before a VALU read here, once per phase.
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 9\n\ts_nop 9");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             i32x4 afn = af;
