@@ -10,18 +10,19 @@
 // which makes room for the row index below it: key = 1024 (pop(q) - ham) - j, largest first =
 // smallest distance first, then lowest index (cv2.BFMatcher's scan order).  One instruction
 // covers 64 bits of 32 x 32 descriptor pairs in about the time the int8 form takes for 32.
-// The index costs no instruction per pair: the accumulator starts from -(row offset inside the
-// tile) (the C operand of the first MFMA), which makes every value relative to its tile's first
-// row, and the two running winners are moved to the next tile's base (+32) once per tile.
+// The index costs no instruction per pair: the accumulator starts from BIAS - (row offset inside
+// the tile) (the C operand of the first MFMA; the bias keeps every value positive), which makes
+// every value relative to its tile's first row, and the two running winners are moved to the
+// next tile's base (+32) once per tile.
 //
 // Structure as the int8 kernel (knn_mfma.hip): block = 4 waves, a wave keeps QT x 32 queries as
 // B operands in VGPRs for the whole scan; train rows are expanded 64 at a time into LDS (double
 // buffered, row stride 32 KM + 16 bytes: conflict-free ds_read_b128 A fragments); a tile's MFMAs
 // are followed by its top-2 update, three waves per SIMD cover each other's waits; one barrier
-// per super-tile.  Keys are exact small integers held
-// in fp32 (|key| < 2^20, biased to be positive), the running top two per lane take 1.25
-// instructions per accumulator (v_max3_i32 on the bit patterns, v_med3_f32); every 1024 rows
-// they are folded into the (distance << 22 | index) keys shared with the other kernels.
+// per super-tile.  The values are exact integers held in fp32 (below 2^23); the running top two
+// per lane take 1.25 instructions per accumulator (v_max3_i32 on the bit patterns, v_med3_f32);
+// every 1024 rows they are folded into the (distance << 22 | index) keys shared with the other
+// kernels.
 #include "knn_common.h"
 
 namespace slam {
