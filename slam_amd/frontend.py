@@ -13,6 +13,8 @@ fast path.
 import math
 import random
 
+import gc
+
 import numpy as np
 import torch
 
@@ -386,6 +388,19 @@ def track_camera_for_many_images(thresh=1, matcher=None, num_of_frames=2560, cam
     The reference constructs its own Matcher on the KITTI images and hard-codes 2560
     frames; here both can be supplied (matcher=..., num_of_frames=...), the defaults keep
     the reference's values.  Returns (camera_positions [F,3], TrackDatabase)."""
+    # The loop allocates tens of thousands of small acyclic objects per frame (DMatch, KeyPoint,
+    # tuples) on top of a heap that keeps growing (the matcher's cache, the track store): the
+    # cyclic collector would rescan all of it again and again for nothing to free.
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        return _track_camera_for_many_images(thresh, matcher, num_of_frames, cameras)
+    finally:
+        if gc_was_on:
+            gc.enable()
+
+
+def _track_camera_for_many_images(thresh, matcher, num_of_frames, cameras):
     k, m1, m2 = cameras if cameras is not None else read_cameras()
     if matcher is None:
         matcher = Matcher(display=VERTICAL_REPRESENTATION)

@@ -18,7 +18,7 @@ import torch
 
 from . import ops
 from .constants import (CONSECUTIVE, FILTERED_MATCHES, FRAMES, HORIZONTAL_REPRESENTATION, LEFT, MATCHES, RIGHT)
-from .types import DMatch, KeyPoint, keypoints_to_array
+from .types import DMatch, keypoints_from_array, keypoints_to_array
 
 
 def _default_device():
@@ -100,11 +100,7 @@ class HipBFMatcher:
         if k not in (1, 2):
             raise ValueError("HipBFMatcher.knnMatch supports k = 1 or 2")
         idx, dist, _ = self.knn_arrays(queryDescriptors, trainDescriptors, k=k)
-        out = []
-        for i in range(idx.shape[0]):
-            row = [DMatch(i, idx[i, c], dist[i, c]) for c in range(k) if idx[i, c] >= 0]
-            out.append(row)
-        return out
+        return _dmatch_lists(idx, dist, k)
 
 
 class PrecomputedFeatures:
@@ -124,7 +120,7 @@ class PrecomputedFeatures:
         side, idx = image
         f = self.frames[idx]
         kp, desc = (f.kpL, f.descL) if side == LEFT else (f.kpR, f.descR)
-        return [KeyPoint(x, y) for x, y in kp], desc
+        return keypoints_from_array(kp), desc
 
     def detect(self, image, mask=None):
         return self.detectAndCompute(image)[0]
@@ -351,7 +347,8 @@ class Matcher:
                                         thr=float(thresh))
             if len(idx) and (idx[:, 1] < 0).any():
                 raise ValueError("not enough values to unpack (expected 2, got 1)")  # the reference's `for m, n in`
-            return [[DMatch(i, idx[i, 0], dist[i, 0])] for i in np.flatnonzero(keep)]
+            rows = np.flatnonzero(keep)
+            return [[DMatch(i, t, d)] for i, t, d in zip(rows.tolist(), idx[rows, 0].tolist(), dist[rows, 0].tolist())]
         matches = self.matcher.knnMatch(ref_dsc, oth_dsc, k=2)
         return Matcher.apply_thresholds(matches, thresh)
 
@@ -397,4 +394,10 @@ def _as_object_array(kps):
 
 
 def _dmatch_lists(idx, dist, k):
-    return [[DMatch(i, idx[i, c], dist[i, c]) for c in range(k) if idx[i, c] >= 0] for i in range(idx.shape[0])]
+    """[n,2] index / distance arrays -> per query a list of up to k DMatch (missing neighbours, index -1,
+    left out).  The arrays go through tolist() first: Python scalars are far cheaper to handle one by
+    one than numpy's."""
+    il, dl = idx.tolist(), dist.tolist()
+    if k == 1:
+        return [[DMatch(i, r[0], d[0])] if r[0] >= 0 else [] for i, (r, d) in enumerate(zip(il, dl))]
+    return [[DMatch(i, r[c], d[c]) for c in range(k) if r[c] >= 0] for i, (r, d) in enumerate(zip(il, dl))]

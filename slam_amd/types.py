@@ -38,8 +38,15 @@ class KeyPoint:
 
 
 def keypoints_from_array(xy):
-    """[N,2] array -> list of KeyPoint."""
-    return [KeyPoint(x, y) for x, y in np.asarray(xy)]
+    """[N,2] array -> list of KeyPoint (pt = the float32 values as Python floats, as cv2 holds them)."""
+    out = []
+    new = KeyPoint.__new__
+    for x, y in np.asarray(xy, dtype=np.float32).reshape(-1, 2).tolist():
+        kp = new(KeyPoint)
+        kp.pt = (x, y)
+        kp.size, kp.angle, kp.response, kp.octave, kp.class_id = 1.0, -1.0, 0.0, 0, -1
+        out.append(kp)
+    return out
 
 
 def keypoints_to_array(kps):
