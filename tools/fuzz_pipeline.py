@@ -15,6 +15,18 @@ from slam_amd import pipeline                                                   
 from slam_amd.synthetic import SyntheticSequence, read_cameras, seeded_hypotheses    # noqa: E402
 
 dev = torch.device("cuda:0")
+USE_L2 = os.environ.get("FUZZ_L2", "0") == "1"     # SIFT-like integer-valued float descriptors, L2 norm
+
+
+def knn(q, t, kk):
+    return oracle.l2_knn(q, t, kk, threads=8) if USE_L2 else oracle.hamming_knn(q, t, kk)
+
+
+def ratio_keep(tidx, tdist, ratio):
+    if not USE_L2:
+        return oracle.ratio_filter(tidx, tdist, ratio)
+    return np.array([i2 >= 0 and float(a) < ratio * float(b) for (a, b), (_, i2) in zip(tdist, tidx)], dtype=np.uint8)
+
 k, m1, m2 = read_cameras()
 P, Q = k @ m1, k @ m2
 bad = 0
@@ -27,6 +39,15 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
     H = int(rng.choice([1, 63, 64, 200, 513]))
     seq = SyntheticSequence(n_kp, n_fr, seed=seed, desc_bytes=D, flip=float(rng.choice([0.02, 0.08, 0.15])),
                             noise=float(rng.choice([0.1, 0.3, 1.0])))
+    if USE_L2:
+        dim = int(rng.choice([64, 128]))
+        proj = rng.integers(0, 2, (D * 8, dim)).astype(np.float32)
+
+        def to_float(desc):        # a fixed random embedding of the bits into integer-valued float dimensions
+            return np.minimum(np.unpackbits(desc, axis=1).astype(np.float32) @ proj, 255.0).astype(np.float32)
+
+        seq.frames = [type(f)(f.kpL, f.kpR, to_float(f.descL), to_float(f.descR), f.idL, f.idR, f.Rt)
+                      for f in seq.frames]
     npair = n_fr - 1
     Rt_host = np.stack([seeded_hypotheses(seq.relative_pose(p, p + 1), H, seed=seed + p) for p in range(npair)])
     fe = pipeline.FrontEnd(k, m1, m2, ratio_thresh=ratio)
@@ -37,7 +58,7 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
     errs = []
     per_frame = []
     for f in seq.frames:
-        idx, _ = oracle.hamming_knn(f.descL, f.descR, 1)
+        idx, _ = knn(f.descL, f.descR, 1)
         keep = oracle.row_filter(idx, f.kpL[:, 1], f.kpR[:, 1], 2.0)
         j = np.where(keep > 0, idx[:, 0], 0)
         X, Y, Z, valid = oracle.triangulate_dlt(P, Q, f.kpL[:, 0], f.kpL[:, 1], f.kpR[j, 0], f.kpR[j, 1])
@@ -51,8 +72,8 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
     cap = ws.cap
     for p in range(npair):
         f1 = seq.frames[p + 1]
-        tidx, tdist = oracle.hamming_knn(seq.frames[p].descL, f1.descL, 2)
-        tkeep = oracle.ratio_filter(tidx, tdist, ratio)
+        tidx, tdist = knn(seq.frames[p].descL, f1.descL, 2)
+        tkeep = ratio_keep(tidx, tdist, ratio)
         rows = oracle.join(tidx, tkeep, per_frame[p][0], per_frame[p][4], per_frame[p + 1][0])
         got = ws.cons.rows.cpu().numpy()[p * cap:p * cap + rows.shape[0]]
         if int(ws.cons.count[p]) != rows.shape[0] or not np.array_equal(got, rows):
