@@ -148,9 +148,9 @@ def main():
     if multi:
         # Two workspaces take turns so that the gather of step i (side stream, RCCL) overlaps the
         # kernels of step i+1; a workspace is reused only after its gather has finished.
-        slots = [(ws, graph, sharding.TableGather(ws, world, rank))]
+        slots = [(ws, graph, sharding.TableGather(ws, world, rank, collective=True))]
         ws_b = fe.prepare(tb, n_hyp=H, want_masks=False, table_pairs=table_pairs, table_rows=table_rows)
-        slots.append((ws_b, try_capture(ws_b), sharding.TableGather(ws_b, world, rank)))
+        slots.append((ws_b, try_capture(ws_b), sharding.TableGather(ws_b, world, rank, collective=True)))
         side = torch.cuda.Stream()
         sent = [None, None]
         step_no = [0]

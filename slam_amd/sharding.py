@@ -88,13 +88,16 @@ class TableGather:
     host memory: a rehearsal path).
     """
 
-    def __init__(self, ws=None, world=1, rank=0, group=None, pose="best_Rt"):
+    def __init__(self, ws=None, world=1, rank=0, group=None, pose="best_Rt", collective=None):
         """pose: which per-pair pose of the workspace travels -- "best_Rt" (winner of a given
-        hypothesis set) or "pose" (result of the device-side RANSAC)."""
+        hypothesis set) or "pose" (result of the device-side RANSAC).
+        collective: go through the process group even with a single rank (default: only when
+        world > 1); lets the collective path be exercised on a one-GPU box."""
         self.ws, self.world, self.rank, self.group, self.pose = ws, world, rank, group, pose
+        self.collective = world > 1 if collective is None else bool(collective)
         self.result = None
         self.fixed = False
-        if ws is not None and world > 1:
+        if ws is not None and self.collective:
             gloo = dist.get_backend(group) == "gloo"
             dev = "cpu" if gloo else ws.arena.device
             mine = torch.tensor([ws.P, ws.layout.pairs, ws.layout.rows], dtype=torch.int64, device=dev)
@@ -117,7 +120,7 @@ class TableGather:
         ws = self.ws
         P = ws.P
         ws.table_views["n_cons"][:P].copy_(ws.cons.count[:P])
-        if self.world == 1:
+        if not self.collective:
             self.result = [self._shard(ws.table_views, P)]
             return self.result
         if not self.fixed:
@@ -138,11 +141,11 @@ class TableGather:
     def gather(self, n_inl, rows, loc, pose, n_cons):
         """Variable-size gather of explicit tables (sizes are exchanged first; one host sync)."""
         world, rank = self.world, self.rank
-        if world > 1 and n_inl.is_cuda and dist.get_backend(self.group) == "gloo":
+        if self.collective and n_inl.is_cuda and dist.get_backend(self.group) == "gloo":
             # rehearsal on a box without one GPU per rank: stage through host memory
             n_inl, rows, loc, pose, n_cons = (t.cpu() for t in (n_inl, rows, loc, pose, n_cons))
         dev = n_inl.device
-        if world == 1:
+        if not self.collective:
             T = int(n_inl.sum().item())
             return [dict(n_inl=n_inl, rows=rows[:T], loc=loc[:T], pose=pose, n_cons=n_cons)]
         # 1. sizes: pairs per rank and total rows per rank (one small all_gather + host sync)
