@@ -306,6 +306,28 @@ int slam_build_inlier_tables(const int32_t *pair_dev, int n_pairs,
                              int32_t *inl_rows_dev, float *inl_loc_dev,
                              int32_t *n_inl_dev, void *stream);
 
+/*
+ * The same tables straight from one pose per pair, packed back to back: the final
+ * find_supporters of the winning pose (utils/utils.py:455), the Rt_inliers list
+ * (utils/utils.py:277-278) and the location lookups (models/TrackDatabase.py:38-46) in one
+ * launch -- no mask, no separate scoring pass, no prefix sum.
+ *
+ * pose [n_pairs,12] f64: the pose whose supporters are tabulated; best_count [n_pairs]: its
+ * supporter count as the scoring pass reported it (slam_select_best), from which pair p's first
+ * output slot is the sum over the pairs before it.  K, t_right, thresh and the consensus
+ * point tables (X .. vR, [n_pairs*cap]) as for slam_score_hypotheses; the verdict per match is
+ * that of its fp64 reference evaluation, so n_inl[p] == best_count[p].
+ */
+int slam_winner_tables(const int32_t *pair_dev, int n_pairs, const int32_t *rows_dev,
+                       const int32_t *count_dev, int cap, const double *K,
+                       const double *t_right, double thresh, const double *pose_dev,
+                       const int32_t *best_count_dev, const double *X_dev,
+                       const double *Y_dev, const double *Z_dev, const float *uL_dev,
+                       const float *vL_dev, const float *uR_dev, const float *vR_dev,
+                       const float *xL_dev, const float *yL_dev, const float *xR_dev,
+                       int32_t *inl_rows_dev, float *inl_loc_dev, int32_t *n_inl_dev,
+                       void *stream);
+
 /* ---- batched PnP-RANSAC around slam_score_hypotheses --------------------------------
  * ransac_for_pnp (utils/utils.py:413-464) for many point sets at once.  The reference
  * draws with Python's global `random`, solves each 4-sample with cv2 (AP3P) and walks the

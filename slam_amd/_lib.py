@@ -28,6 +28,7 @@ EXPORTS = (
     "slam_score_hypotheses_range",
     "slam_select_best",
     "slam_build_inlier_tables",
+    "slam_winner_tables",
     "slam_ransac_sample",
     "slam_p3p_hypotheses",
     "slam_ransac_select",
@@ -92,6 +93,8 @@ def load():
     lib.slam_select_best.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
     lib.slam_build_inlier_tables.restype = ci
     lib.slam_build_inlier_tables.argtypes = [vp, ci, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.slam_winner_tables.restype = ci
+    lib.slam_winner_tables.argtypes = [vp, ci, vp, vp, ci, vp, vp, cd] + [vp] * 16
     lib.slam_ransac_sample.restype = ci
     lib.slam_ransac_sample.argtypes = [ctypes.c_uint64, ci, ci, vp, ci, vp, vp]
     lib.slam_p3p_hypotheses.restype = ci

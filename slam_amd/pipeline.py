@@ -231,8 +231,16 @@ class FrontEnd:
         st = self.lib.slam_select_best(_p(ws.counts), _p(Rt), ws.P, ws.H, _p(ws.best), _p(ws.best_count),
                                        _p(ws.best_Rt), stream)
         _lib.check(st, "slam_select_best")
+        if dense:           # supporter test of the winner, compaction and packing in one launch
+            c, tb = ws.cons, ws.tb
+            st = self.lib.slam_winner_tables(_p(ws.pair), ws.P, _p(c.rows), _p(c.count), ws.cap, ws.hK, ws.hT,
+                                             self.pix_thresh, _p(ws.best_Rt), _p(ws.best_count), _p(c.X), _p(c.Y),
+                                             _p(c.Z), _p(c.uL), _p(c.vL), _p(c.uR), _p(c.vR), _p(tb.xL), _p(tb.yL),
+                                             _p(tb.xR), _p(ws.inl_rows), _p(ws.inl_loc), _p(ws.n_inl), stream)
+            _lib.check(st, "slam_winner_tables")
+            return
         self._score_one(ws, ws.best_Rt, stream)
-        self._tables(ws, stream, dense=dense)
+        self._tables(ws, stream, dense=False)
 
     # -- device-side RANSAC ----------------------------------------------------
     def prepare_ransac(self, ws):
