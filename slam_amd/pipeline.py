@@ -225,9 +225,10 @@ class FrontEnd:
         _lib.check(st, "slam_score_hypotheses")
 
     def select(self, ws, Rt, stream, dense=True):
-        """Winner per pair (first best), its supporter mask (one more scoring call with
-        H = 1, as the reference's final find_supporters, utils/utils.py:455) and the
-        order-preserving inlier tables; dense=True packs the pairs back to back."""
+        """Winner per pair (first best), its supporters (the reference's final find_supporters,
+        utils/utils.py:455) and the order-preserving inlier tables.  dense=True packs the pairs
+        back to back and tests the winner's supporters inside the table kernel; dense=False
+        scores the winner once more with a mask and leaves each pair in its own slot."""
         st = self.lib.slam_select_best(_p(ws.counts), _p(Rt), ws.P, ws.H, _p(ws.best), _p(ws.best_count),
                                        _p(ws.best_Rt), stream)
         _lib.check(st, "slam_select_best")

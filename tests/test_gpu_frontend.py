@@ -236,3 +236,34 @@ def test_graph_replay_matches_plain_launches(device):
         assert n_i > 0
         # second trial: other hypotheses written into the same tensor
         Rt.copy_(torch.from_numpy(np.ascontiguousarray(Rt_host[:, ::-1])).to(device))
+
+
+def test_winner_tables_match_the_mask_path(device):
+    """slam_winner_tables (flags of the winner recomputed beside the compaction) against the
+    longer route through the C ABI: one-hypothesis scoring with a supporter mask, prefix sum,
+    slam_build_inlier_tables.  Ragged pairs, one of them empty."""
+    k, m1, m2 = read_cameras()
+    seq = SyntheticSequence(500, 6, seed=23)
+    f = seq.frames[3]                                    # pairs 2 and 3 have no consensus matches
+    seq.frames[3] = type(f)(f.kpL[:0], f.kpR[:0], f.descL[:0], f.descR[:0], f.idL[:0], f.idR[:0], f.Rt)
+    P, H = 5, 200
+    Rt_host = np.stack([seeded_hypotheses(seq.relative_pose(p, p + 1), H, seed=40 + p) for p in range(P)])
+    fe = pipeline.FrontEnd(k, m1, m2)
+    tb = pipeline.FrameTables.from_frames(seq.frames, device)
+    ws = fe.prepare(tb, n_hyp=H)
+    Rt = torch.from_numpy(Rt_host).to(device)
+    fe.run(ws, Rt)
+    torch.cuda.synchronize()
+    fused = {n: getattr(ws, n).clone() for n in ("n_inl", "inl_rows", "inl_loc")}
+    total = int(fused["n_inl"].sum())
+    assert total > 0 and int(fused["n_inl"][2]) == 0 and int(fused["n_inl"][3]) == 0
+    assert torch.equal(fused["n_inl"].view(-1)[:P], ws.best_count.view(-1)[:P])
+    for n in fused:
+        getattr(ws, n).fill_(0)
+    stream = torch.cuda.current_stream().cuda_stream
+    fe._score_one(ws, ws.best_Rt, stream)
+    fe._tables(ws, stream, dense=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ws.n_inl, fused["n_inl"])
+    assert torch.equal(ws.inl_rows[:total], fused["inl_rows"][:total])
+    assert torch.equal(ws.inl_loc[:total], fused["inl_loc"][:total])
