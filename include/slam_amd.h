@@ -260,6 +260,8 @@ int slam_score_hypotheses(const double *Rt_dev, int n_sets, int H,
  * slice of the hypotheses, lets the stopping rule decide which sets are finished, and scores
  * the rest only for the others -- the reference never scores a hypothesis after its loop has
  * stopped either (utils/utils.py:425).  Masks need the full range and no skip list.
+ * work_ready != 0: work_dev still holds what an earlier call prepared for the same points,
+ * camera and threshold (the call then skips that preparation).
  */
 int slam_score_hypotheses_range(const double *Rt_dev, int n_sets, int H_total,
                                 int h_begin, int H, const int32_t *skip_dev,
@@ -270,7 +272,7 @@ int slam_score_hypotheses_range(const double *Rt_dev, int n_sets, int H_total,
                                 const float *vR_dev, int cap, const int32_t *n_dev,
                                 int n_host, double thresh, int32_t *counts_dev,
                                 uint64_t *masks_dev, int mask_words,
-                                double *work_dev, void *stream);
+                                double *work_dev, int work_ready, void *stream);
 
 /*
  * Winner of a scored hypothesis set: the FIRST hypothesis with the largest
@@ -400,6 +402,22 @@ int slam_refine_poses(const double *K_host, const double *X_dev, const double *Y
                       const uint64_t *masks_dev, int mask_words,
                       const double *Rt0_dev, int n_sets, int iterations,
                       double *Rt_out_dev, int32_t *ok_dev, void *stream);
+
+/*
+ * The tail of ransac_for_pnp in one launch (utils/utils.py:449-455): the supporters of the
+ * winner Rt0 are found here with the supporter test of slam_score_hypotheses (no mask is
+ * handed over), the pose is refined on them as slam_refine_poses does, and
+ * ref_count [n_sets] receives the number of supporters of Rt_out -- the count the final
+ * find_supporters call reports.  uR, vR, t_right, thresh as in slam_score_hypotheses.
+ */
+int slam_refine_winners(const double *K_host, const double *t_right_host, double thresh,
+                        const double *X_dev, const double *Y_dev, const double *Z_dev,
+                        const float *uL_dev, const float *vL_dev,
+                        const float *uR_dev, const float *vR_dev,
+                        int cap, const int32_t *n_dev, int n_host,
+                        const double *Rt0_dev, int n_sets, int iterations,
+                        double *Rt_out_dev, int32_t *ok_dev, int32_t *ref_count_dev,
+                        void *stream);
 
 /*
  * Final choice (utils/utils.py:455-463): out_Rt = refined pose when its supporter count

@@ -33,6 +33,7 @@ EXPORTS = (
     "slam_p3p_hypotheses",
     "slam_ransac_select",
     "slam_refine_poses",
+    "slam_refine_winners",
     "slam_ransac_adopt",
 )
 
@@ -88,7 +89,7 @@ def load():
     lib.slam_score_hypotheses.argtypes = [vp, ci, ci, vp, vp] + [vp] * 7 + [ci, vp, ci, cd, vp, vp, ci, vp, vp]
     lib.slam_score_hypotheses_range.restype = ci
     lib.slam_score_hypotheses_range.argtypes = ([vp, ci, ci, ci, ci, vp, vp, vp] + [vp] * 7 +
-                                                [ci, vp, ci, cd, vp, vp, ci, vp, vp])
+                                                [ci, vp, ci, cd, vp, vp, ci, vp, ci, vp])
     lib.slam_select_best.restype = ci
     lib.slam_select_best.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
     lib.slam_build_inlier_tables.restype = ci
@@ -103,6 +104,8 @@ def load():
     lib.slam_ransac_select.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp]
     lib.slam_refine_poses.restype = ci
     lib.slam_refine_poses.argtypes = [vp] * 6 + [ci, vp, ci, vp, ci, vp, ci, ci, vp, vp, vp]
+    lib.slam_refine_winners.restype = ci
+    lib.slam_refine_winners.argtypes = [vp, vp, cd] + [vp] * 7 + [ci, vp, ci, vp, ci, ci, vp, vp, vp, vp]
     lib.slam_ransac_adopt.restype = ci
     lib.slam_ransac_adopt.argtypes = [ci, vp, ci, ci] + [vp] * 8
     _lib = lib

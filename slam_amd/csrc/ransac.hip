@@ -9,6 +9,7 @@
 // sequential stopping rule is applied afterwards to the counts, which selects exactly the
 // hypothesis the one-by-one loop would have stopped with for the same draws.
 #include "common.h"
+#include "supports.h"
 
 namespace slam {
 namespace {
@@ -430,16 +431,20 @@ constexpr int NSUM = 28;   // 21 upper-triangle entries of J^T J, 6 of J^T r, th
 
 struct RefineArgs {
     double fx, fy, cx, cy;
+    Mat33 K;          // the supporter test (used when masks is null, and for ref_count)
+    Vec3 tr;
+    double thresh;
     const double *X, *Y, *Z;
-    const float *uL, *vL;
+    const float *uL, *vL, *uR, *vR;
     int cap;
     const int32_t *n_dev;
     int n_host;
-    const unsigned long long *masks;
+    const unsigned long long *masks;   // supporters of Rt0 given by the caller, or null: tested here
     int mask_words;
     const double *Rt0;
     double *Rt_out;
     int32_t *ok;
+    int32_t *ref_count;                // supporters of Rt_out, or null
     int iterations;
 };
 
@@ -467,63 +472,127 @@ __device__ __forceinline__ void exp_so3(const double *w, double *E)
         }
 }
 
-// Solves the 6x6 system M x = rhs (Gaussian elimination, partial pivoting); false if singular.
-__device__ bool solve6(double (&M)[6][6], double (&rhs)[6], double (&x)[6])
+// The value another lane of the same 16-lane row holds (CTRL: the operand-permute pattern).
+template <int CTRL>
+__device__ __forceinline__ double row_peer(double v)
 {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int plo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    const int phi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(phi, plo);
+}
+
+// Solves the 6x6 system M x = rhs (Gaussian elimination, partial pivoting); false if singular.
+// Every index is a compile-time constant (the row exchange is a chain of selects), so the
+// matrix lives in registers.
+__device__ __forceinline__ bool solve6(double (&M)[6][6], double (&rhs)[6], double (&x)[6])
+{
+    bool ok = true;
+#pragma unroll
     for (int c = 0; c < 6; ++c) {
         int piv = c;
         double big = fabs(M[c][c]);
+#pragma unroll
         for (int r = c + 1; r < 6; ++r)
             if (fabs(M[r][c]) > big) {
                 big = fabs(M[r][c]);
                 piv = r;
             }
-        if (!(big > 0.0) || !isfinite(big))
-            return false;
-        if (piv != c) {
-            for (int k = 0; k < 6; ++k) {
-                const double tmp = M[c][k];
-                M[c][k] = M[piv][k];
-                M[piv][k] = tmp;
+        ok = ok && big > 0.0 && isfinite(big);
+#pragma unroll
+        for (int r = c + 1; r < 6; ++r) {
+            const bool sw = piv == r;
+#pragma unroll
+            for (int k = c; k < 6; ++k) {   // columns left of c are never read again
+                const double up = M[c][k], dn = M[r][k];
+                M[c][k] = sw ? dn : up;
+                M[r][k] = sw ? up : dn;
             }
-            const double tmp = rhs[c];
-            rhs[c] = rhs[piv];
-            rhs[piv] = tmp;
+            const double up = rhs[c], dn = rhs[r];
+            rhs[c] = sw ? dn : up;
+            rhs[r] = sw ? up : dn;
         }
+#pragma unroll
         for (int r = c + 1; r < 6; ++r) {
             const double f = M[r][c] / M[c][c];
+#pragma unroll
             for (int k = c; k < 6; ++k)
                 M[r][k] -= f * M[c][k];
             rhs[r] -= f * rhs[c];
         }
     }
+#pragma unroll
     for (int r = 5; r >= 0; --r) {
         double s = rhs[r];
+#pragma unroll
         for (int k = r + 1; k < 6; ++k)
             s -= M[r][k] * x[k];
         x[r] = s / M[r][r];
     }
-    return true;
+    return ok;
 }
 
 // Levenberg-Marquardt on the left-image reprojection error over the supporters of the winning
 // hypothesis, started from it (the job SOLVEPNP_ITERATIVE does at utils/utils.py:452).
-// One block per point set; every iteration is one block-wide reduction of NSUM sums.
-__global__ void __launch_bounds__(256) refine_kernel(const RefineArgs a)
+// One block per point set; every iteration is one block-wide reduction of NSUM sums.  Thread t
+// owns points t, t+256, ...: the first REFINE_JREG of them stay in registers for all iterations
+// (an iteration then touches no memory but LDS), later ones are re-read.
+constexpr int REFINE_JREG = 6;
+
+__global__ void __launch_bounds__(256, 2) refine_kernel(const RefineArgs a)
 {
     __shared__ double part[4][NSUM];
-    __shared__ double sums[NSUM];
-    __shared__ double pose[12], cand[12];
+    __shared__ double rowsum[16][NSUM];
+    __shared__ double sums[NSUM], accepted[NSUM];
+    __shared__ double pose[12], cand[12], pose0[12];
     __shared__ int state;   // 0 = iterate, 1 = finished
     const int set = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int n = a.n_dev ? a.n_dev[set] : a.n_host;
     n = min(max(n, 0), a.cap);
-    const unsigned long long *mask = a.masks + (size_t)set * a.mask_words;
+    const unsigned long long *mask = a.masks ? a.masks + (size_t)set * a.mask_words : nullptr;
     const size_t pbase = (size_t)set * a.cap;
     if (tid < 12)
-        pose[tid] = cand[tid] = a.Rt0[(size_t)set * 12 + tid];
+        pose[tid] = cand[tid] = pose0[tid] = a.Rt0[(size_t)set * 12 + tid];
     __syncthreads();
+
+    // is point i a supporter of the starting pose?
+    auto starts_in = [&](int i, double X, double Y, double Z, float u, float v) -> bool {
+        if (mask)
+            return (mask[i >> 6] >> (i & 63)) & 1ull;
+        return supports(pose0, a.K, a.tr, X, Y, Z, (double)u, (double)v, (double)a.uR[pbase + i],
+                        (double)a.vR[pbase + i], a.thresh);
+    };
+
+    double pX[REFINE_JREG], pY[REFINE_JREG], pZ[REFINE_JREG];
+    float pu[REFINE_JREG], pv[REFINE_JREG];
+    unsigned reg_in = 0;                 // bit j: point tid + 256 j (j < REFINE_JREG) is a supporter
+    unsigned long long later_in = 0;     // the same for the next 64 points of this thread
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < REFINE_JREG; ++j) {
+        const int i = tid + 256 * j;
+        const bool valid = i < n;
+        pX[j] = valid ? a.X[pbase + i] : 0.0;
+        pY[j] = valid ? a.Y[pbase + i] : 0.0;
+        pZ[j] = valid ? a.Z[pbase + i] : 1.0;
+        pu[j] = valid ? a.uL[pbase + i] : 0.0f;
+        pv[j] = valid ? a.vL[pbase + i] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < REFINE_JREG; ++j) {
+        const int i = tid + 256 * j;
+        if (i < n && starts_in(i, pX[j], pY[j], pZ[j], pu[j], pv[j])) {
+            reg_in |= 1u << j;
+            ++cnt;
+        }
+    }
+    for (int j = REFINE_JREG, i = tid + 256 * REFINE_JREG; i < n; ++j, i += 256) {
+        const bool in = starts_in(i, a.X[pbase + i], a.Y[pbase + i], a.Z[pbase + i], a.uL[pbase + i], a.vL[pbase + i]);
+        if (in && j - REFINE_JREG < 64)
+            later_in |= 1ull << (j - REFINE_JREG);
+        cnt += in ? 1 : 0;
+    }
 
     // cost, J^T J and J^T r at the pose in `cand`, over the supporters; result in sums[]
     auto accumulate = [&]() {
@@ -535,16 +604,13 @@ __global__ void __launch_bounds__(256) refine_kernel(const RefineArgs a)
 #pragma unroll
         for (int k = 0; k < 12; ++k)
             R[k] = cand[k];
-        for (int i = tid; i < n; i += 256) {
-            if (!((mask[i >> 6] >> (i & 63)) & 1ull))
-                continue;
-            const double X = a.X[pbase + i], Y = a.Y[pbase + i], Z = a.Z[pbase + i];
+        auto add_point = [&](double X, double Y, double Z, float u, float v) {
             const double y0 = R[0] * X + R[1] * Y + R[2] * Z + R[3];
             const double y1 = R[4] * X + R[5] * Y + R[6] * Z + R[7];
             const double y2 = R[8] * X + R[9] * Y + R[10] * Z + R[11];
             const double iz = 1.0 / y2;
-            const double r0 = a.fx * y0 * iz + a.cx - (double)a.uL[pbase + i];
-            const double r1 = a.fy * y1 * iz + a.cy - (double)a.vL[pbase + i];
+            const double r0 = a.fx * y0 * iz + a.cx - (double)u;
+            const double r1 = a.fy * y1 * iz + a.cy - (double)v;
             // d(proj)/dY rows and the two Jacobian rows over (rotation, translation)
             const double du0 = a.fx * iz, du2 = -a.fx * y0 * iz * iz;
             const double dv1 = a.fy * iz, dv2 = -a.fy * y1 * iz * iz;
@@ -560,30 +626,42 @@ __global__ void __launch_bounds__(256) refine_kernel(const RefineArgs a)
             for (int p = 0; p < 6; ++p)
                 acc[21 + p] += Ju[p] * r0 + Jv[p] * r1;
             acc[27] += r0 * r0 + r1 * r1;
+        };
+#pragma unroll
+        for (int j = 0; j < REFINE_JREG; ++j)
+            if ((reg_in >> j) & 1u)
+                add_point(pX[j], pY[j], pZ[j], pu[j], pv[j]);
+        for (int j = REFINE_JREG, i = tid + 256 * REFINE_JREG; i < n; ++j, i += 256) {
+            const double X = a.X[pbase + i], Y = a.Y[pbase + i], Z = a.Z[pbase + i];
+            const float u = a.uL[pbase + i], v = a.vL[pbase + i];
+            const bool in = j - REFINE_JREG < 64 ? (later_in >> (j - REFINE_JREG)) & 1ull : starts_in(i, X, Y, Z, u, v);
+            if (in)
+                add_point(X, Y, Z, u, v);
         }
+        // 16-lane rows first, through the lane-permuting operand path of the vector ALU (four
+        // steps, no LDS round trip), then the 16 row sums of the block through LDS
 #pragma unroll
         for (int k = 0; k < NSUM; ++k) {
             double v = acc[k];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1)
-                v += __shfl_xor(v, off);
-            if (lane == 0)
-                part[wave][k] = v;
+            v += row_peer<0xB1>(v);    // quad_perm [1,0,3,2]
+            v += row_peer<0x4E>(v);    // quad_perm [2,3,0,1]
+            v += row_peer<0x141>(v);   // row_half_mirror
+            v += row_peer<0x140>(v);   // row_mirror
+            if ((lane & 15) == 0)
+                rowsum[tid >> 4][k] = v;
         }
         __syncthreads();
-        if (tid < NSUM)
-            sums[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+        if (tid < NSUM) {
+            double t = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                t += rowsum[r][tid];
+            sums[tid] = t;
+        }
         __syncthreads();
     };
 
     // supporters
-    int cnt = 0;
-    for (int w = tid; w < (n + 63) / 64; w += 256) {
-        unsigned long long m = mask[w];
-        if (w == (n >> 6) && (n & 63))
-            m &= (1ull << (n & 63)) - 1ull;
-        cnt += __popcll(m);
-    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
         cnt += __shfl_xor(cnt, off);
@@ -596,31 +674,28 @@ __global__ void __launch_bounds__(256) refine_kernel(const RefineArgs a)
     bool good = n_sup >= 3;
     if (good) {
         accumulate();
-        // thread 0 carries the solver state
-        double Hm[21], g[6], cost = sums[27], lam = 1e-3;
-        if (tid == 0) {
-#pragma unroll
-            for (int k = 0; k < 21; ++k)
-                Hm[k] = sums[k];
-#pragma unroll
-            for (int k = 0; k < 6; ++k)
-                g[k] = sums[21 + k];
+        // thread 0 carries the solver state; the normal equations of the accepted pose wait in LDS
+        double cost = sums[27], lam = 1e-3;
+        if (tid < 27)
+            accepted[tid] = sums[tid];
+        if (tid == 0)
             state = isfinite(cost) ? 0 : 2;   // 2 = failed
-        }
         __syncthreads();
         for (int it = 0; it < a.iterations && state == 0; ++it) {
             if (tid == 0) {
                 double M[6][6], rhs[6], step[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-                int k = 0;
+#pragma unroll
                 for (int p = 0; p < 6; ++p)
+#pragma unroll
                     for (int q = p; q < 6; ++q) {
-                        M[p][q] = Hm[k];
-                        M[q][p] = Hm[k];
-                        ++k;
+                        const int k = p * 6 - p * (p - 1) / 2 + (q - p);   // upper triangle, row-major
+                        M[p][q] = accepted[k];
+                        M[q][p] = accepted[k];
                     }
+#pragma unroll
                 for (int p = 0; p < 6; ++p) {
                     M[p][p] += lam * (M[p][p] + 1e-12);
-                    rhs[p] = -g[p];
+                    rhs[p] = -accepted[21 + p];
                 }
                 const bool solved = solve6(M, rhs, step);
                 const double tmax = fmax(fmax(fabs(pose[3]), fabs(pose[7])), fabs(pose[11]));
@@ -650,12 +725,8 @@ __global__ void __launch_bounds__(256) refine_kernel(const RefineArgs a)
 #pragma unroll
                     for (int k = 0; k < 12; ++k)
                         pose[k] = cand[k];
-#pragma unroll
-                    for (int k = 0; k < 21; ++k)
-                        Hm[k] = sums[k];
-#pragma unroll
-                    for (int k = 0; k < 6; ++k)
-                        g[k] = sums[21 + k];
+                    for (int k = 0; k < 27; ++k)
+                        accepted[k] = sums[k];
                     const bool small = cost - c2 < 1e-14 * fmax(cost, 1e-300);
                     cost = c2;
                     if (small)
@@ -697,12 +768,40 @@ __global__ void __launch_bounds__(256) refine_kernel(const RefineArgs a)
         double *o = a.Rt_out + (size_t)set * 12;
         for (int i = 0; i < 3; ++i) {
             for (int j = 0; j < 3; ++j)
-                o[4 * i + j] = good ? R[3 * i + j] : a.Rt0[(size_t)set * 12 + 4 * i + j];
-            o[4 * i + 3] = good ? pose[4 * i + 3] : a.Rt0[(size_t)set * 12 + 4 * i + 3];
+                o[4 * i + j] = cand[4 * i + j] = good ? R[3 * i + j] : pose0[4 * i + j];
+            o[4 * i + 3] = cand[4 * i + 3] = good ? pose[4 * i + 3] : pose0[4 * i + 3];
         }
         if (a.ok)
             a.ok[set] = good ? 1 : 0;
     }
+    if (!a.ref_count)
+        return;
+    // supporters of the pose just written (utils/utils.py:455)
+    __syncthreads();
+    double F[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+        F[k] = cand[k];
+    int ref = 0;
+#pragma unroll
+    for (int j = 0; j < REFINE_JREG; ++j) {
+        const int i = tid + 256 * j;
+        if (i < n && supports(F, a.K, a.tr, pX[j], pY[j], pZ[j], (double)pu[j], (double)pv[j], (double)a.uR[pbase + i],
+                              (double)a.vR[pbase + i], a.thresh))
+            ++ref;
+    }
+    for (int i = tid + 256 * REFINE_JREG; i < n; i += 256)
+        if (supports(F, a.K, a.tr, a.X[pbase + i], a.Y[pbase + i], a.Z[pbase + i], (double)a.uL[pbase + i],
+                     (double)a.vL[pbase + i], (double)a.uR[pbase + i], (double)a.vR[pbase + i], a.thresh))
+            ++ref;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        ref += __shfl_xor(ref, off);
+    if (lane == 0)
+        part[wave][0] = (double)ref;
+    __syncthreads();
+    if (tid == 0)
+        a.ref_count[set] = (int)(part[0][0] + part[1][0] + part[2][0] + part[3][0]);
 }
 
 // Final choice (utils/utils.py:453-463): the refined pose replaces the winner when it has at least
@@ -824,33 +923,39 @@ extern "C" int slam_ransac_select(const int32_t *counts, const double *Rt, int n
     return check_launch("slam_ransac_select");
 }
 
-extern "C" int slam_refine_poses(const double *K, const double *X, const double *Y, const double *Z, const float *uL,
-                                 const float *vL, int cap, const int32_t *n_dev, int n_host, const uint64_t *masks,
-                                 int mask_words, const double *Rt0, int n_sets, int iterations, double *Rt_out,
-                                 int32_t *ok, void *stream)
+namespace {
+int launch_refine(const char *who, const double *K, const double *t_right, double thresh, const double *X,
+                  const double *Y, const double *Z, const float *uL, const float *vL, const float *uR, const float *vR,
+                  int cap, const int32_t *n_dev, int n_host, const uint64_t *masks, int mask_words, const double *Rt0,
+                  int n_sets, int iterations, double *Rt_out, int32_t *ok, int32_t *ref_count, void *stream)
 {
     if (n_sets < 0 || cap < 0 || iterations < 0)
-        return fail(SLAM_ERR_BAD_ARG, "slam_refine_poses: negative size");
+        return fail(SLAM_ERR_BAD_ARG, "%s: negative size", who);
     if (!K)
-        return fail(SLAM_ERR_BAD_ARG, "slam_refine_poses: null intrinsics");
+        return fail(SLAM_ERR_BAD_ARG, "%s: null intrinsics", who);
     if (!pinhole(K))
-        return fail(SLAM_ERR_BAD_ARG, "slam_refine_poses: K must be a finite pinhole matrix [fx 0 cx; 0 fy cy; 0 0 1]");
+        return fail(SLAM_ERR_BAD_ARG, "%s: K must be a finite pinhole matrix [fx 0 cx; 0 fy cy; 0 0 1]", who);
     if (n_sets == 0)
         return SLAM_OK;
-    if (!masks || !Rt0 || !Rt_out || (cap > 0 && (!X || !Y || !Z || !uL || !vL)))
-        return fail(SLAM_ERR_BAD_ARG, "slam_refine_poses: null buffer");
-    if (mask_words < (cap + 63) / 64)
-        return fail(SLAM_ERR_BAD_ARG, "slam_refine_poses: mask_words %d < ceil(cap/64)", mask_words);
+    if (!Rt0 || !Rt_out || (cap > 0 && (!X || !Y || !Z || !uL || !vL)))
+        return fail(SLAM_ERR_BAD_ARG, "%s: null buffer", who);
     RefineArgs a;
     a.fx = K[0];
     a.fy = K[4];
     a.cx = K[2];
     a.cy = K[5];
+    for (int i = 0; i < 9; ++i)
+        a.K.m[i] = K[i];
+    for (int i = 0; i < 3; ++i)
+        a.tr.v[i] = t_right ? t_right[i] : 0.0;
+    a.thresh = thresh;
     a.X = X;
     a.Y = Y;
     a.Z = Z;
     a.uL = uL;
     a.vL = vL;
+    a.uR = uR;
+    a.vR = vR;
     a.cap = cap;
     a.n_dev = n_dev;
     a.n_host = n_host;
@@ -859,9 +964,36 @@ extern "C" int slam_refine_poses(const double *K, const double *X, const double 
     a.Rt0 = Rt0;
     a.Rt_out = Rt_out;
     a.ok = ok;
+    a.ref_count = ref_count;
     a.iterations = iterations;
     hipLaunchKernelGGL(refine_kernel, dim3(n_sets), dim3(256), 0, (hipStream_t)stream, a);
-    return check_launch("slam_refine_poses");
+    return check_launch(who);
+}
+}  // namespace
+
+extern "C" int slam_refine_poses(const double *K, const double *X, const double *Y, const double *Z, const float *uL,
+                                 const float *vL, int cap, const int32_t *n_dev, int n_host, const uint64_t *masks,
+                                 int mask_words, const double *Rt0, int n_sets, int iterations, double *Rt_out,
+                                 int32_t *ok, void *stream)
+{
+    if (n_sets > 0 && !masks)
+        return fail(SLAM_ERR_BAD_ARG, "slam_refine_poses: null buffer");
+    if (n_sets > 0 && cap >= 0 && mask_words < (cap + 63) / 64)
+        return fail(SLAM_ERR_BAD_ARG, "slam_refine_poses: mask_words %d < ceil(cap/64)", mask_words);
+    return launch_refine("slam_refine_poses", K, nullptr, 0.0, X, Y, Z, uL, vL, nullptr, nullptr, cap, n_dev, n_host,
+                         masks, mask_words, Rt0, n_sets, iterations, Rt_out, ok, nullptr, stream);
+}
+
+extern "C" int slam_refine_winners(const double *K, const double *t_right, double thresh, const double *X,
+                                   const double *Y, const double *Z, const float *uL, const float *vL, const float *uR,
+                                   const float *vR, int cap, const int32_t *n_dev, int n_host, const double *Rt0,
+                                   int n_sets, int iterations, double *Rt_out, int32_t *ok, int32_t *ref_count,
+                                   void *stream)
+{
+    if (n_sets > 0 && (!t_right || !ref_count || (cap > 0 && (!uR || !vR))))
+        return fail(SLAM_ERR_BAD_ARG, "slam_refine_winners: null buffer");
+    return launch_refine("slam_refine_winners", K, t_right, thresh, X, Y, Z, uL, vL, uR, vR, cap, n_dev, n_host, nullptr,
+                         0, Rt0, n_sets, iterations, Rt_out, ok, ref_count, stream);
 }
 
 extern "C" int slam_ransac_adopt(int n_sets, const int32_t *n_dev, int n_host, int cap, const int32_t *best_count,

@@ -421,13 +421,19 @@ __global__ void __launch_bounds__(256) score_fast_kernel(const ScoreArgs a)
 // queue and settled by Lane64::eval after the loop.  "Sure in" is impossible when |hz| is below the rounding noise of its own
 // sum, and "sure out" there needs a projected pixel hundreds of thresholds away, so the
 // division in supports() cannot disagree.
+//
+// SPLIT: for few hypotheses per set (the first slice of the batched RANSAC) a block takes 64
+// hypotheses and its four wavefronts a quarter of the points each, summed through LDS at the
+// end -- four times the wavefronts in flight for the same work.
+template <bool SPLIT>
 __global__ void __launch_bounds__(256) score_mixed_kernel(const ScoreArgs a)
 {
     const int set = blockIdx.x / a.blocks_per_set;
     const int blk = blockIdx.x - set * a.blocks_per_set;
-    const int h = blk * 256 + threadIdx.x;
-    if ((blk * 256 + (int)(threadIdx.x & ~63u)) >= a.H || (a.skip && a.skip[set]))
-        return;  // whole wavefront past the last hypothesis, or a set that is not to be scored
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int h = SPLIT ? blk * 64 + (int)(threadIdx.x & 63u) : blk * 256 + (int)threadIdx.x;
+    if ((SPLIT ? blk * 64 : blk * 256 + 64 * wave) >= a.H || (a.skip && a.skip[set]))
+        return;  // whole wavefront (SPLIT: block) past the last hypothesis, or a set that is not to be scored
     const bool live = h < a.H;
     const double *hdr = score_hdr(a) + SCORE_HDR * set;
     const double Amax = hdr[0], Umax = hdr[1], Wmax = hdr[2];
@@ -485,7 +491,17 @@ __global__ void __launch_bounds__(256) score_mixed_kernel(const ScoreArgs a)
     int n = a.n_dev ? a.n_dev[set] : a.n_host;
     n = min(max(n, 0), a.cap);
     n = __builtin_amdgcn_readfirstlane(n);
-    const float *__restrict__ recs32 = score_recs32(a) + (size_t)SCORE_REC32 * ((size_t)set * a.cap);
+    // this wavefront's points: pairs [pair0, pair0 + n_pairs), and the odd last point for its owner
+    int pair0 = 0, n_pairs = n >> 1;
+    if (SPLIT) {
+        const int q = ((n >> 1) + 3) >> 2;
+        pair0 = min(wave * q, n >> 1);
+        n_pairs = min(q, (n >> 1) - pair0);
+    }
+    const bool owns_tail = !SPLIT || wave == 3;
+    const int pt0 = 2 * pair0, pt_end = owns_tail ? n : pt0 + 2 * n_pairs;
+    const float *__restrict__ recs32 =
+        score_recs32(a) + (size_t)SCORE_REC32 * ((size_t)set * a.cap) + (size_t)SCORE_REC32 * pt0;
     const double *__restrict__ recs64 = score_recs64(a) + (size_t)SCORE_REC * ((size_t)set * a.cap);
     int cnt = 0;
 
@@ -523,7 +539,6 @@ __global__ void __launch_bounds__(256) score_mixed_kernel(const ScoreArgs a)
     unsigned bits = 0;
     int qn = 0;
     bool full = !f32_ok && !dead;
-    const int n_pairs = n >> 1;
     auto push = [&](int i) __attribute__((always_inline)) {
         if (dead)
             return;
@@ -543,11 +558,11 @@ __global__ void __launch_bounds__(256) score_mixed_kernel(const ScoreArgs a)
             if (pair < n_pairs) {   // the clamped duplicate of an odd pair count is dropped below
                 if (!s0) {
                     bits &= ~2u;
-                    push(2 * pair);
+                    push(pt0 + 2 * pair);
                 }
                 if (!s1) {
                     bits &= ~1u;
-                    push(2 * pair + 1);
+                    push(pt0 + 2 * pair + 1);
                 }
             }
         }
@@ -575,22 +590,24 @@ __global__ void __launch_bounds__(256) score_mixed_kernel(const ScoreArgs a)
             bits = 0;
         }
     }
-    if ((n & 1) && __ballot(!full) != 0ull) {
-        // odd point count: the last point alone through the fp32 stage
-        const float *r = recs32 + (size_t)SCORE_REC32 * (n - 1);
-        float p1[SCORE_REC32];
+    if ((n & 1) && owns_tail) {
+        if (__ballot(!full) != 0ull) {
+            // odd point count: the last point alone through the fp32 stage
+            const float *r = recs32 + (size_t)SCORE_REC32 * (n - 1 - pt0);
+            float p1[SCORE_REC32];
 #pragma unroll
-        for (int c = 0; c < SCORE_REC32; ++c)
-            p1[c] = r[c];
-        float d;
-        bool sure;
-        eval32(p1, d, sure);
-        if (sure)
-            cnt += d < 0.0f ? 1 : 0;
-        else
+            for (int c = 0; c < SCORE_REC32; ++c)
+                p1[c] = r[c];
+            float d;
+            bool sure;
+            eval32(p1, d, sure);
+            if (sure)
+                cnt += d < 0.0f ? 1 : 0;
+            else
+                push(n - 1);
+        } else {
             push(n - 1);
-    } else if (n & 1) {
-        push(n - 1);
+        }
     }
     // settle the queues: lane-private point indices, fp64 filter / reference evaluation
     // (the reference evaluation itself: only the pose has to be live here, which keeps the
@@ -618,15 +635,23 @@ __global__ void __launch_bounds__(256) score_mixed_kernel(const ScoreArgs a)
     }
     if (__ballot(full) != 0ull) {
         int cnt64 = 0;
-        for (int i = 0; i < n; ++i)
+        for (int i = pt0; i < pt_end; ++i)
             cnt64 += eval64(i) ? 1 : 0;
         if (full)
             cnt = cnt64;
     }
     if (dead)
         cnt = 0;
-    if (live)
+    if (SPLIT) {
+        __shared__ int quarter[4][64];
+        quarter[wave][threadIdx.x & 63u] = cnt;
+        __syncthreads();
+        if (wave == 0 && live)
+            a.counts[(size_t)set * a.Hs + h] =
+                (quarter[0][threadIdx.x] + quarter[1][threadIdx.x]) + (quarter[2][threadIdx.x] + quarter[3][threadIdx.x]);
+    } else if (live) {
         a.counts[(size_t)set * a.Hs + h] = cnt;
+    }
 }
 
 // ---- matrix-core variant -----------------------------------------------------------------
@@ -957,7 +982,7 @@ extern "C" int slam_score_hypotheses(const double *Rt, int n_sets, int H, const 
                                      double *work, void *stream)
 {
     return slam_score_hypotheses_range(Rt, n_sets, H, 0, H, nullptr, K, t_right, X, Y, Z, uL, vL, uR, vR, cap, n_dev,
-                                       n_host, thresh, counts, masks, mask_words, work, stream);
+                                       n_host, thresh, counts, masks, mask_words, work, 0, stream);
 }
 
 extern "C" int slam_score_hypotheses_range(const double *Rt, int n_sets, int H_total, int h_begin, int H,
@@ -965,7 +990,8 @@ extern "C" int slam_score_hypotheses_range(const double *Rt, int n_sets, int H_t
                                            const double *X, const double *Y, const double *Z, const float *uL,
                                            const float *vL, const float *uR, const float *vR, int cap,
                                            const int32_t *n_dev, int n_host, double thresh, int32_t *counts,
-                                           uint64_t *masks, int mask_words, double *work, void *stream)
+                                           uint64_t *masks, int mask_words, double *work, int work_ready,
+                                           void *stream)
 {
     if (n_sets < 0 || H < 0 || cap < 0 || h_begin < 0 || H_total < 0)
         return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: negative size");
@@ -1027,13 +1053,16 @@ extern "C" int slam_score_hypotheses_range(const double *Rt, int n_sets, int H_t
         pinhole = pinhole && (t_right[i] - t_right[i] == 0.0);
     if (work && !masks && pinhole && cap > 0) {
         a.n_rec = (size_t)n_sets * cap;
-        hipError_t e = hipMemsetAsync(work + SCORE_WORK_PER_REC * a.n_rec, 0, sizeof(double) * SCORE_HDR * (size_t)n_sets, s);
-        if (e != hipSuccess)
-            return fail(SLAM_ERR_LAUNCH, "slam_score_hypotheses: %s", hipGetErrorString(e));
-        const int chunks = (cap + 255) / 256;
-        if ((long long)n_sets * chunks > 0x7FFFFFFFLL)
-            return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: grid too large");
-        hipLaunchKernelGGL(score_prep_kernel, dim3((unsigned)(n_sets * chunks)), dim3(256), 0, s, a, chunks);
+        if (!work_ready) {
+            hipError_t e =
+                hipMemsetAsync(work + SCORE_WORK_PER_REC * a.n_rec, 0, sizeof(double) * SCORE_HDR * (size_t)n_sets, s);
+            if (e != hipSuccess)
+                return fail(SLAM_ERR_LAUNCH, "slam_score_hypotheses: %s", hipGetErrorString(e));
+            const int chunks = (cap + 255) / 256;
+            if ((long long)n_sets * chunks > 0x7FFFFFFFLL)
+                return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: grid too large");
+            hipLaunchKernelGGL(score_prep_kernel, dim3((unsigned)(n_sets * chunks)), dim3(256), 0, s, a, chunks);
+        }
         a.blocks_per_set = (H + 255) / 256;
         const long long blocks = (long long)n_sets * a.blocks_per_set;
         if (blocks > 0x7FFFFFFFLL)
@@ -1052,8 +1081,13 @@ extern "C" int slam_score_hypotheses_range(const double *Rt, int n_sets, int H_t
                 if (mblocks > 0x7FFFFFFFLL)
                     return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: grid too large");
                 hipLaunchKernelGGL(score_mfma_kernel, dim3((unsigned)mblocks), dim3(256), 0, s, a);
+            } else if ((long long)n_sets * ((H + 63) / 64) < 3072) {
+                // fewer than three wavefronts per SIMD: split the points of a set over a block
+                a.blocks_per_set = (H + 63) / 64;
+                hipLaunchKernelGGL(score_mixed_kernel<true>, dim3((unsigned)(n_sets * a.blocks_per_set)), dim3(256), 0, s,
+                                   a);
             } else {
-                hipLaunchKernelGGL(score_mixed_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+                hipLaunchKernelGGL(score_mixed_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
             }
         } else {
             hipLaunchKernelGGL(score_fast_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);

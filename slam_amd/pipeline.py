@@ -300,10 +300,11 @@ class FrontEnd:
             _lib.check(st, "slam_p3p_hypotheses")
 
         def score_range(h0, hn, skip):
+            # (the second slice reuses the point records the first one prepared)
             st = lib.slam_score_hypotheses_range(_p(ws.Rt_gen), ws.P, ws.H, h0, hn, _p(skip), ws.hK, ws.hT, _p(c.X),
                                                  _p(c.Y), _p(c.Z), _p(c.uL), _p(c.vL), _p(c.uR), _p(c.vR), ws.cap,
                                                  _p(c.count), 0, self.pix_thresh, _p(ws.counts), None, 0,
-                                                 _p(ws.score_work), stream)
+                                                 _p(ws.score_work), 1 if h0 > 0 else 0, stream)
             _lib.check(st, "slam_score_hypotheses_range")
 
         def select(n_avail):
@@ -325,16 +326,21 @@ class FrontEnd:
             solve_range(first, n_used - first, ws.stopped)
             score_range(first, n_used - first, ws.stopped)
             select(n_used)
-        self._score_one(ws, ws.best_Rt, stream)
-        _lib.check(lib.slam_refine_poses(ws.hK, _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL), _p(c.vL), ws.cap, _p(c.count), 0,
-                                         _p(ws.final_mask), max(ws.mask_words, 1), _p(ws.best_Rt), ws.P,
-                                         int(refine_iterations), _p(ws.ref_Rt), _p(ws.ref_ok), stream),
-                   "slam_refine_poses")
-        self._score_one(ws, ws.ref_Rt, stream)          # the mask and ratio reported are the refined pose's
+        # supporters of the winner, refinement on them and the refined pose's supporter count in
+        # one launch; the tables are the refined pose's (the reference reports its mask and ratio
+        # whether or not the refined pose is adopted)
+        _lib.check(lib.slam_refine_winners(ws.hK, ws.hT, self.pix_thresh, _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL), _p(c.vL),
+                                           _p(c.uR), _p(c.vR), ws.cap, _p(c.count), 0, _p(ws.best_Rt), ws.P,
+                                           int(refine_iterations), _p(ws.ref_Rt), _p(ws.ref_ok), _p(ws.final_count),
+                                           stream), "slam_refine_winners")
         _lib.check(lib.slam_ransac_adopt(ws.P, _p(c.count), 0, ws.cap, _p(ws.best_count), _p(ws.final_count),
                                          _p(ws.best_Rt), _p(ws.ref_Rt), _p(ws.pose), _p(ws.ratio), _p(ws.found),
                                          stream), "slam_ransac_adopt")
-        self._tables(ws, stream)
+        tb = ws.tb
+        _lib.check(lib.slam_winner_tables(_p(ws.pair), ws.P, _p(c.rows), _p(c.count), ws.cap, ws.hK, ws.hT,
+                                          self.pix_thresh, _p(ws.ref_Rt), _p(ws.final_count), _p(c.X), _p(c.Y), _p(c.Z),
+                                          _p(c.uL), _p(c.vL), _p(c.uR), _p(c.vR), _p(tb.xL), _p(tb.yL), _p(tb.xR),
+                                          _p(ws.inl_rows), _p(ws.inl_loc), _p(ws.n_inl), stream), "slam_winner_tables")
 
     def run_ransac(self, ws, seed, max_iterations=None, first_slice=128):
         """Stages 1-4 followed by the device-side RANSAC, all on the current stream."""

@@ -167,6 +167,49 @@ def test_refinement_matches_the_host_solver(device):
     assert int(ok[0]) == 0 and np.array_equal(Rt.cpu().numpy()[0], start.reshape(12))
 
 
+def test_fused_refinement_matches_the_three_launch_route(device):
+    """slam_refine_winners against mask scoring + slam_refine_poses + scoring of the result: the
+    same poses bit for bit and the same counts.  Set sizes on both sides of what a thread keeps
+    in registers (6 points), of its flag word (70) and beyond; an empty set; a NaN start."""
+    k, m1, m2 = read_cameras()
+    t_right = m2[:, 3]
+    rng = np.random.default_rng(17)
+    sizes = [900, 1536, 1537, 4000, 18300, 0, 700]
+    cap = max(sizes)
+    S = len(sizes)
+    X = np.zeros((S, cap, 3))
+    uvL = np.zeros((S, cap, 2), np.float32)
+    uvR = np.zeros((S, cap, 2), np.float32)
+    start = np.zeros((S, 12))
+    for s, n in enumerate(sizes):
+        Xs, uv, pose = _scene(rng, max(n, 1), k, noise=0.6)
+        Ys = Xs @ pose[:, :3].T + pose[:, 3]
+        uR = (k[0, 0] * (Ys[:, 0] + t_right[0]) / Ys[:, 2] + k[0, 2] + rng.normal(0, 0.6, len(Ys))).astype(np.float32)
+        bad = rng.random(len(Ys)) < 0.3                                   # outliers: far-off pixels
+        uv[bad] += rng.normal(0, 30, (int(bad.sum()), 2)).astype(np.float32)
+        X[s, :n], uvL[s, :n], uvR[s, :n, 0], uvR[s, :n, 1] = Xs[:n], uv[:n], uR[:n], uv[:n, 1]
+        st = pose.copy()
+        st[:, :3] = rodrigues(rng.normal(0, 2e-3, 3)) @ st[:, :3]
+        st[:, 3] += rng.normal(0, 0.02, 3)
+        start[s] = st.reshape(12)
+    start[6] = np.nan
+    n_dev = _t(np.array(sizes, np.int32), device)
+    pts = [_t(a.reshape(-1), device) for a in (X[..., 0], X[..., 1], X[..., 2], uvL[..., 0], uvL[..., 1], uvR[..., 0],
+                                                uvR[..., 1])]
+    Rt0 = _t(start, device)
+    c0, m0 = ops.score_hypotheses(Rt0.reshape(S, 1, 3, 4), k, t_right, *pts, thresh=2.0, cap=cap, n_dev=n_dev,
+                                  want_masks=True)
+    Rt_a, ok_a = ops.refine_poses(k, *pts[:5], cap, n_dev, m0.reshape(S, -1), Rt0)
+    c_a = ops.score_hypotheses(Rt_a.reshape(S, 1, 3, 4), k, t_right, *pts, thresh=2.0, cap=cap, n_dev=n_dev, fast=False)
+    Rt_b, ok_b, c_b = ops.refine_winners(k, t_right, *pts, cap, n_dev, Rt0, thresh=2.0)
+    assert np.array_equal(Rt_a.cpu().numpy(), Rt_b.cpu().numpy(), equal_nan=True)
+    assert torch.equal(ok_a, ok_b) and torch.equal(c_a.reshape(-1), c_b)
+    assert ok_b.cpu().tolist() == [1, 1, 1, 1, 1, 0, 0]
+    got = c_b.cpu().numpy()
+    assert (got[:5] > 0.4 * np.array(sizes[:5])).all() and got[5] == 0 and got[6] == 0
+    assert (got[:5] >= c0.reshape(-1).cpu().numpy()[:5] - 5).all()        # refinement keeps (about) every supporter
+
+
 def test_device_ransac_end_to_end(device):
     k, m1, m2 = read_cameras()
     seq = SyntheticSequence(1200, 5, seed=21)

@@ -33,11 +33,23 @@ for H in (1000, 10000):
         "select": lambda: lib.slam_ransac_select(_p(ws.counts), _p(ws.Rt_gen), ws.P, ws.H, ws.H, _p(c.count), 0, ws.cap, H,
                                                  _p(ws.best), _p(ws.best_count), _p(ws.best_Rt), _p(ws.iters),
                                                  _p(ws.stopped), stream),
-        "score_one": lambda: fe._score_one(ws, ws.best_Rt, stream),
-        "refine": lambda: lib.slam_refine_poses(ws.hK, _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL), _p(c.vL), ws.cap, _p(c.count), 0,
-                                                _p(ws.final_mask), max(ws.mask_words, 1), _p(ws.best_Rt), ws.P, 30,
-                                                _p(ws.ref_Rt), _p(ws.ref_ok), stream),
-        "tables": lambda: fe._tables(ws, stream),
+        "first_slice_p3p": lambda: lib.slam_p3p_hypotheses(ws.hK, _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL), _p(c.vL), ws.cap,
+                                                           _p(c.count), 0, _p(ws.samples), ws.P, ws.H, 0, 128, None,
+                                                           _p(ws.Rt_gen), stream),
+        "first_slice_score": lambda: lib.slam_score_hypotheses_range(
+            _p(ws.Rt_gen), ws.P, ws.H, 0, 128, None, ws.hK, ws.hT, _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL), _p(c.vL), _p(c.uR),
+            _p(c.vR), ws.cap, _p(c.count), 0, fe.pix_thresh, _p(ws.counts), None, 0, _p(ws.score_work), 0, stream),
+        "refine_winners": lambda: lib.slam_refine_winners(ws.hK, ws.hT, fe.pix_thresh, _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL),
+                                                          _p(c.vL), _p(c.uR), _p(c.vR), ws.cap, _p(c.count), 0,
+                                                          _p(ws.best_Rt), ws.P, 30, _p(ws.ref_Rt), _p(ws.ref_ok),
+                                                          _p(ws.final_count), stream),
+        "adopt": lambda: lib.slam_ransac_adopt(ws.P, _p(c.count), 0, ws.cap, _p(ws.best_count), _p(ws.final_count),
+                                               _p(ws.best_Rt), _p(ws.ref_Rt), _p(ws.pose), _p(ws.ratio), _p(ws.found),
+                                               stream),
+        "winner_tables": lambda: lib.slam_winner_tables(
+            _p(ws.pair), ws.P, _p(c.rows), _p(c.count), ws.cap, ws.hK, ws.hT, fe.pix_thresh, _p(ws.ref_Rt),
+            _p(ws.final_count), _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL), _p(c.vL), _p(c.uR), _p(c.vR), _p(ws.tb.xL), _p(ws.tb.yL),
+            _p(ws.tb.xR), _p(ws.inl_rows), _p(ws.inl_loc), _p(ws.n_inl), stream),
         "whole_ransac_one_phase": lambda: fe.ransac(ws, 6, stream, first_slice=0),
         "whole_ransac": lambda: fe.ransac(ws, 6, stream),
         "whole_front_end": lambda: fe.run_ransac(ws, 6),
@@ -47,11 +59,11 @@ for H in (1000, 10000):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         fn()
         e0.record()
-        for _ in range(5):
+        for _ in range(20):
             fn()
         e1.record()
         torch.cuda.synchronize()
-        out[name] = round(e0.elapsed_time(e1) / 5, 4)
+        out[name] = round(e0.elapsed_time(e1) / 20, 4)
     it = ws.iters.cpu().numpy()[:P]
     print(f"H={H} pairs={P}: ms per stage {out}; mean iterations the rule ran {it.mean():.1f}; "
           f"pairs/s whole front-end {P / (out['whole_front_end'] * 1e-3):.0f}")
