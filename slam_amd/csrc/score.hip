@@ -182,7 +182,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 // magnitude bounds (non-negative doubles order like their bit patterns, so an integer atomic
 // max does it).  A NaN magnitude maps to the largest pattern and ends up disabling the
 // filters for the set.
-__global__ void __launch_bounds__(256) score_prep_kernel(const ScoreArgs a, int chunks_per_set)
+__global__ void __launch_bounds__(256) score_prep_kernel(const ScoreArgs a, int chunks_per_set, bool want_bf16)
 {
     __shared__ unsigned long long red[3][4];
     const int set = blockIdx.x / chunks_per_set;
@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(256) score_prep_kernel(const ScoreArgs a, int 
         // k-slot layout of the matrix-core kernel: slots 9t + 3i + j (t = X, Y, Z) pair piece i
         // of a coefficient with piece j of the coordinate; slots 27..29 pair the constant term's
         // pieces with 1.0; slots 30, 31 are unused
-        {
+        if (want_bf16) {
             const float c3[3] = {(float)X, (float)Y, (float)Z};
             uint32_t pc[3][3];
 #pragma unroll
@@ -1053,6 +1053,11 @@ extern "C" int slam_score_hypotheses_range(const double *Rt, int n_sets, int H_t
         pinhole = pinhole && (t_right[i] - t_right[i] == 0.0);
     if (work && !masks && pinhole && cap > 0) {
         a.n_rec = (size_t)n_sets * cap;
+        // SLAM_SCORE_IMPL=f64 keeps the fp64-only filter kernel for rectified stereo (A/B timing),
+        // SLAM_SCORE_IMPL=bf16 the matrix-core variant; the counts are identical either way.
+        const char *impl = getenv("SLAM_SCORE_IMPL");
+        const bool f64_only = impl && impl[0] == 'f' && impl[1] == '6';
+        const bool use_mfma = impl && impl[0] == 'b';
         if (!work_ready) {
             hipError_t e =
                 hipMemsetAsync(work + SCORE_WORK_PER_REC * a.n_rec, 0, sizeof(double) * SCORE_HDR * (size_t)n_sets, s);
@@ -1061,18 +1066,13 @@ extern "C" int slam_score_hypotheses_range(const double *Rt, int n_sets, int H_t
             const int chunks = (cap + 255) / 256;
             if ((long long)n_sets * chunks > 0x7FFFFFFFLL)
                 return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: grid too large");
-            hipLaunchKernelGGL(score_prep_kernel, dim3((unsigned)(n_sets * chunks)), dim3(256), 0, s, a, chunks);
+            hipLaunchKernelGGL(score_prep_kernel, dim3((unsigned)(n_sets * chunks)), dim3(256), 0, s, a, chunks, use_mfma);
         }
         a.blocks_per_set = (H + 255) / 256;
         const long long blocks = (long long)n_sets * a.blocks_per_set;
         if (blocks > 0x7FFFFFFFLL)
             return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: grid too large");
-        // SLAM_SCORE_IMPL=f64 keeps the fp64-only filter kernel for rectified stereo (A/B timing);
-        // the counts are identical either way.
-        const char *impl = getenv("SLAM_SCORE_IMPL");
-        const bool f64_only = impl && impl[0] == 'f' && impl[1] == '6';
         if (t_right[1] == 0.0 && t_right[2] == 0.0) {
-            const bool use_mfma = impl && impl[0] == 'b';   // SLAM_SCORE_IMPL=bf16: the matrix-core variant
             if (f64_only) {
                 hipLaunchKernelGGL(score_fast_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
             } else if (use_mfma) {
