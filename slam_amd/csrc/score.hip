@@ -1081,8 +1081,9 @@ extern "C" int slam_score_hypotheses_range(const double *Rt, int n_sets, int H_t
                 if (mblocks > 0x7FFFFFFFLL)
                     return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: grid too large");
                 hipLaunchKernelGGL(score_mfma_kernel, dim3((unsigned)mblocks), dim3(256), 0, s, a);
-            } else if ((long long)n_sets * ((H + 63) / 64) < 3072) {
+            } else if ((impl && impl[0] == 's') || (!(impl && impl[0] == 'w') && (long long)n_sets * ((H + 63) / 64) < 3072)) {
                 // fewer than three wavefronts per SIMD: split the points of a set over a block
+                // (SLAM_SCORE_IMPL=split / wide force one form or the other, for tests and timing)
                 a.blocks_per_set = (H + 63) / 64;
                 hipLaunchKernelGGL(score_mixed_kernel<true>, dim3((unsigned)(n_sets * a.blocks_per_set)), dim3(256), 0, s,
                                    a);
