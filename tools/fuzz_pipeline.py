@@ -2,7 +2,7 @@
 """End-to-end fuzz of the batched front-end against the CPU oracle: random sequences (keypoint count,
 frame count, descriptor length, bit-flip rate, pixel noise, ratio threshold, hypothesis count), every
 stage compared exactly -- stereo map, triangulation validity, consensus rows, supporter counts of
-every hypothesis, winner and inlier count."""
+every hypothesis, winner, inlier count, inlier rows and feature locations."""
 import os
 import sys
 
@@ -69,6 +69,7 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
         errs.append("triangulation validity")
     counts = ws.counts.cpu().numpy()
     n_inl = ws.n_inl.cpu().numpy()
+    inl_rows, inl_loc = ws.inl_rows.cpu().numpy(), ws.inl_loc.cpu().numpy()
     cap = ws.cap
     for p in range(npair):
         f1 = seq.frames[p + 1]
@@ -88,6 +89,19 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
             errs.append(f"supporter counts of pair {p}")
         if int(ws.best[p]) != int(np.argmax(rc)) or n_inl[p] != rc.max():
             errs.append(f"winner of pair {p}")
+            continue
+        # the winner's inlier rows and feature locations, packed back to back in pair order
+        _, wmask = oracle.score_hypotheses(Rt_host[p][int(np.argmax(rc))][None], k, m2[:, 3], *pts, 2.0, want_masks=True)
+        bits = np.unpackbits(wmask[0].view(np.uint8), bitorder="little")[:rows.shape[0]].astype(bool)
+        off = int(n_inl[:p].sum())
+        want_rows = rows[bits]
+        f0 = seq.frames[p]
+        want_loc = np.stack([f0.kpL[want_rows[:, 0], 0], f0.kpR[want_rows[:, 1], 0], f0.kpL[want_rows[:, 0], 1],
+                             f1.kpL[want_rows[:, 2], 0], f1.kpR[want_rows[:, 3], 0], f1.kpL[want_rows[:, 2], 1]], axis=1)
+        if not np.array_equal(inl_rows[off:off + len(want_rows)], want_rows):
+            errs.append(f"inlier rows of pair {p}")
+        if not np.array_equal(inl_loc[off:off + len(want_rows)], want_loc.astype(np.float32)):
+            errs.append(f"inlier locations of pair {p}")
     tag = "ok " if not errs else "BAD"
     print(f"seed {seed}: {tag} kp {n_kp} frames {n_fr} D {D} ratio {ratio} H {H} consensus "
           f"{ws.cons.count.cpu().numpy()[:npair].tolist()} {'; '.join(errs)}", flush=True)
