@@ -732,6 +732,8 @@ __global__ void __launch_bounds__(256, 2) refine_kernel(const RefineArgs a)
                     if (small)
                         state = 1;
                     lam = fmax(lam * 0.3, 1e-12);
+                } else if (isfinite(c2) && c2 - cost <= 1e-12 * cost) {
+                    state = 1;   // the step moves the cost by less than its rounding noise: at the optimum
                 } else {
                     lam *= 10.0;
                     if (lam > 1e12)

@@ -173,6 +173,8 @@ def refine_pnp(points_3d, points_2d, K, Rt0, iterations=30):
                 break
             cost = c2
             lam = max(lam * 0.3, 1e-12)
+        elif np.isfinite(c2) and c2 - cost <= 1e-12 * cost:
+            break                                  # the step moves the cost by less than its rounding noise
         else:
             lam *= 10.0
             if lam > 1e12:
