@@ -288,6 +288,10 @@ def rodriguez_to_mat(rvec, tvec):
                       np.asarray(tvec, dtype=np.float64).reshape(3, 1)))
 
 
+# Hypotheses drawn, solved and scored per GPU call: the first chunk is small because the stop
+# rule usually fires within a handful of iterations (every solve past it is wasted host time),
+# later chunks double up to the cap.
+_RANSAC_FIRST_CHUNK = 8
 _RANSAC_CHUNK = 32
 
 
@@ -331,8 +335,10 @@ def ransac_on_arrays(X, uvL, uvR, intrinsic_matrix, right_camera_matrix, thresh=
     epsilon = 0.99
     I = max_iterations
     i = 0
+    chunk_size = _RANSAC_FIRST_CHUNK
     while i < I and epsilon != 0:
-        chunk = min(_RANSAC_CHUNK, I - i)
+        chunk = min(chunk_size, I - i)
+        chunk_size = min(2 * chunk_size, _RANSAC_CHUNK)
         states, poses = [], []
         for _ in range(chunk):
             states.append(random.getstate())

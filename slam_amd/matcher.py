@@ -18,7 +18,7 @@ import torch
 
 from . import ops
 from .constants import (CONSECUTIVE, FILTERED_MATCHES, FRAMES, HORIZONTAL_REPRESENTATION, LEFT, MATCHES, RIGHT)
-from .types import DMatch, keypoints_from_array, keypoints_to_array
+from .types import DMatch, keypoint_object_array, keypoints_from_array, keypoints_to_array
 
 
 def _default_device():
@@ -194,6 +194,12 @@ class Matcher:
         kpi = self.get_kp(frameId)[loc]
         x, y = kpi[kp].pt
         return x, y
+
+    def feature_location_arrays(self, frameId):
+        """([N,2] float32 left pixels, [M,2] float32 right pixels) of a cached frame: what
+        get_feature_location_frame reads one keypoint at a time."""
+        kpl, kpr = self.get_kp(frameId)
+        return keypoints_to_array(kpl), keypoints_to_array(kpr)
 
     def get_dsc(self):
         return self._img1_dsc, self._img2_dsc
@@ -387,10 +393,7 @@ class Matcher:
 
 def _as_object_array(kps):
     """np.copy(list of keypoints) as the reference stores it: a 1-D object array."""
-    arr = np.empty(len(kps), dtype=object)
-    for i, kp in enumerate(kps):
-        arr[i] = kp
-    return arr
+    return keypoint_object_array(kps)
 
 
 def _dmatch_lists(idx, dist, k):

@@ -94,6 +94,15 @@ class TrackDatabase:
     def update_tracks_from_frame(self, matcher, frameId, matches_kp_indices_and_3d_points):
         """Rows are (prev_left, prev_right, cur_left, cur_right, X); pixel locations come
         from matcher.get_feature_location_frame (models/TrackDatabase.py:34-53)."""
+        arrays = getattr(matcher, "feature_location_arrays", None)
+        if arrays is not None and len(matches_kp_indices_and_3d_points) > 0:
+            # the same rows through the table form: pixel locations gathered as arrays
+            rows = np.array([m[:4] for m in matches_kp_indices_and_3d_points], dtype=np.int64).reshape(-1, 4)
+            (pl, pr), (cl, cr) = arrays(frameId), arrays(frameId + 1)
+            loc = np.stack([pl[rows[:, 0], 0], pr[rows[:, 1], 0], pl[rows[:, 0], 1],
+                            cl[rows[:, 2], 0], cr[rows[:, 3], 0], cl[rows[:, 2], 1]], axis=1)
+            self.update_tracks_from_tables(frameId, rows, loc)
+            return
         self.prepare_to_next_pair(frameId)
         for prev_left, prev_right, cur_left, cur_right, _ in matches_kp_indices_and_3d_points:
             xl, yl = matcher.get_feature_location_frame(frameId, kp=prev_left, loc=LEFT)

@@ -37,11 +37,40 @@ class KeyPoint:
         return f"KeyPoint{self.pt}"
 
 
+class KeyPointList(list):
+    """A list of KeyPoint that remembers the [N,2] float32 array it was made from, so that code
+    which needs the coordinates as an array does not walk the objects again.  The array is
+    trusted only while the list still has its length (callers above the front-end never edit
+    keypoints in place)."""
+    __slots__ = ("array",)
+
+
+class KeyPointArray(np.ndarray):
+    """The 1-D object array of KeyPoint the matcher cache holds (models/Matcher.py:118-119), with
+    the same remembered coordinate array; views and slices of it do not inherit the coordinates."""
+
+    def __array_finalize__(self, obj):
+        self.array = None
+
+
+def keypoint_object_array(kps):
+    """list of KeyPoint -> 1-D object array of the same objects (np.copy of a keypoint list, as the
+    reference stores it), carrying the coordinate array when the list has one."""
+    out = np.empty(len(kps), dtype=object).view(KeyPointArray)
+    for i, kp in enumerate(kps):
+        out[i] = kp
+    coords = getattr(kps, "array", None)
+    out.array = coords if coords is not None and coords.shape[0] == len(kps) else None
+    return out
+
+
 def keypoints_from_array(xy):
     """[N,2] array -> list of KeyPoint (pt = the float32 values as Python floats, as cv2 holds them)."""
-    out = []
+    arr = np.ascontiguousarray(np.asarray(xy, dtype=np.float32).reshape(-1, 2))
+    out = KeyPointList()
+    out.array = arr
     new = KeyPoint.__new__
-    for x, y in np.asarray(xy, dtype=np.float32).reshape(-1, 2).tolist():
+    for x, y in arr.tolist():
         kp = new(KeyPoint)
         kp.pt = (x, y)
         kp.size, kp.angle, kp.response, kp.octave, kp.class_id = 1.0, -1.0, 0.0, 0, -1
@@ -53,4 +82,7 @@ def keypoints_to_array(kps):
     """Sequence of objects with .pt -> [N,2] float32."""
     if isinstance(kps, np.ndarray) and kps.dtype != object:
         return np.ascontiguousarray(kps, dtype=np.float32).reshape(-1, 2)
+    arr = getattr(kps, "array", None)
+    if arr is not None and arr.shape[0] == len(kps):
+        return arr
     return np.array([kp.pt for kp in kps], dtype=np.float32).reshape(-1, 2)
