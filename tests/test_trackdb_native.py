@@ -83,3 +83,37 @@ def test_native_replay_is_faster():
     assert got == want
     print(f"python {t1 - t0:.3f} s, native {t2 - t1:.3f} s for {int(n_inl.sum())} rows")
     assert (t2 - t1) < (t1 - t0)
+
+
+def test_frame_update_through_tables_equals_the_row_loop():
+    """update_tracks_from_frame with a matcher that hands out coordinate arrays (the table
+    route) builds the same store as the keypoint-by-keypoint route of the reference
+    (models/TrackDatabase.py:34-53)."""
+    from slam_amd.matcher import Matcher, PrecomputedFeatures
+    from slam_amd.synthetic import SyntheticSequence
+
+    seq = SyntheticSequence(300, 4, seed=5)
+    matcher = Matcher(algo=PrecomputedFeatures(seq.frames))
+    for i in range(4):
+        matcher.read_images(i)
+        matcher.detect_and_compute(i)
+
+    class RowsOnly:                       # the reference's view of a matcher: one keypoint at a time
+        def get_feature_location_frame(self, frameId, kp, loc):
+            return matcher.get_feature_location_frame(frameId, kp, loc)
+
+    rng = np.random.default_rng(2)
+    a, b = TrackDatabase(), TrackDatabase()
+    prev_cur = rng.permutation(300)[:150]
+    for frame in range(3):
+        m = 0 if frame == 1 else 120      # a pair without inliers in the middle
+        prev_left = rng.permutation(prev_cur)[:m]
+        cur_left = rng.integers(0, 300, m)
+        rows = [(int(p), int(rng.integers(0, 300)), int(c), int(rng.integers(0, 300)), np.zeros(3))
+                for p, c in zip(prev_left, cur_left)]
+        a.update_tracks_from_frame(matcher, frame, rows)
+        b.update_tracks_from_frame(RowsOnly(), frame, rows)
+        prev_cur = cur_left if m else prev_cur
+    assert a == b and a.get_num_tracks() > 0
+    t = next(iter(a._tracks.values()))
+    assert type(t[0][0]) is int and all(type(v) is float for v in t[0][1])
