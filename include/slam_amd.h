@@ -224,6 +224,26 @@ int slam_join_consensus(const int32_t *pair_dev, int n_pairs, int max_nq,
                         void *stream);
 
 /*
+ * The same join which also fills the scoring workspace of slam_score_hypotheses for the
+ * consensus sets it emits (point records and per-set bounds, for intrinsics K_host and the
+ * scoring threshold thresh), so that the scoring call on these sets can be made with
+ * work_ready = 1 (slam_score_hypotheses_range) and skips its own preparation pass.
+ * score_work_dev: 24 * n_pairs * max(cap, 1) doubles, 16-byte aligned; NULL = plain join.
+ */
+int slam_join_consensus_prepared(const int32_t *pair_dev, int n_pairs, int max_nq,
+                                 const int32_t *t_idx_dev, const uint8_t *t_keep_dev,
+                                 const int32_t *stereo_map_dev,
+                                 const uint8_t *valid3d_dev, const double *X_dev,
+                                 const double *Y_dev, const double *Z_dev,
+                                 const float *xL_dev, const float *yL_dev,
+                                 const float *xR_dev, const float *yR_dev, int cap,
+                                 int32_t *rows_dev, double *cX_dev, double *cY_dev,
+                                 double *cZ_dev, float *cuL_dev, float *cvL_dev,
+                                 float *cuR_dev, float *cvR_dev, int32_t *count_dev,
+                                 const double *K_host, double thresh,
+                                 double *score_work_dev, void *stream);
+
+/*
  * PnP-RANSAC hypothesis scoring: supporters of H candidate poses.
  * Replaces: find_supporters (utils/utils.py:389-410) as called once per RANSAC
  * iteration and once after refinement by ransac_for_pnp (utils/utils.py:433,455).

@@ -24,6 +24,7 @@ EXPORTS = (
     "slam_triangulate_dlt",
     "slam_triangulate_matched",
     "slam_join_consensus",
+    "slam_join_consensus_prepared",
     "slam_score_hypotheses",
     "slam_score_hypotheses_range",
     "slam_select_best",
@@ -85,6 +86,8 @@ def load():
     lib.slam_triangulate_matched.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.slam_join_consensus.restype = ci
     lib.slam_join_consensus.argtypes = [vp, ci, ci] + [vp] * 11 + [ci] + [vp] * 9 + [vp]
+    lib.slam_join_consensus_prepared.restype = ci
+    lib.slam_join_consensus_prepared.argtypes = [vp, ci, ci] + [vp] * 11 + [ci] + [vp] * 9 + [vp, cd, vp, vp]
     lib.slam_score_hypotheses.restype = ci
     lib.slam_score_hypotheses.argtypes = [vp, ci, ci, vp, vp] + [vp] * 7 + [ci, vp, ci, cd, vp, vp, ci, vp, vp]
     lib.slam_score_hypotheses_range.restype = ci

@@ -4,6 +4,7 @@
 // reference's operation order, one IEEE rounding per operation, so supporter
 // decisions are reproducible bit for bit on any IEEE machine.
 #include "common.h"
+#include "score_records.h"
 
 namespace slam {
 
@@ -217,11 +218,17 @@ struct JoinArgs {
     double *cX, *cY, *cZ;
     float *cuL, *cvL, *cuR, *cvR;
     int32_t *count;
+    // optional: the scoring workspace of the same point sets, filled on the way
+    double *score_work;
+    size_t n_rec;
+    double fx, fy, cx, cy, thr;
 };
 
 __global__ void __launch_bounds__(256) join_kernel(const JoinArgs a)
 {
     __shared__ int wave_tot[4];
+    __shared__ unsigned long long red[3][4];
+    unsigned long long am = 0ull, um = 0ull, wm = 0ull;
     const int32_t *pr = a.pair + SLAM_PAIR_STRIDE * blockIdx.x;
     const int p0 = pr[0], pn = pr[1], c0 = pr[2], cn = pr[3], t0 = pr[4], r0 = pr[5];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -251,19 +258,46 @@ __global__ void __launch_bounds__(256) join_kernel(const JoinArgs a)
         if (take && slot < a.cap) {
             const size_t o = (size_t)blockIdx.x * a.cap + slot;
             reinterpret_cast<int4 *>(a.rows)[o] = make_int4(q, pr_right, t, cr_right);
-            a.cX[o] = a.X[p0 + q];
-            a.cY[o] = a.Y[p0 + q];
-            a.cZ[o] = a.Z[p0 + q];
-            a.cuL[o] = a.xL[c0 + t];
-            a.cvL[o] = a.yL[c0 + t];
-            a.cuR[o] = a.xR[r0 + cr_right];
-            a.cvR[o] = a.yR[r0 + cr_right];
+            const double X = a.X[p0 + q], Y = a.Y[p0 + q], Z = a.Z[p0 + q];
+            const float uL = a.xL[c0 + t], vL = a.yL[c0 + t], uR = a.xR[r0 + cr_right], vR = a.yR[r0 + cr_right];
+            a.cX[o] = X;
+            a.cY[o] = Y;
+            a.cZ[o] = Z;
+            a.cuL[o] = uL;
+            a.cvL[o] = vL;
+            a.cuR[o] = uR;
+            a.cvR[o] = vR;
+            if (a.score_work)
+                score_write_record(a.score_work, a.n_rec, o, X, Y, Z, uL, vL, uR, vR, a.fx, a.fy, a.cx, a.cy, a.thr, am, um,
+                                   wm);
         }
         base += total;
         __syncthreads();
     }
     if (tid == 0)
         a.count[blockIdx.x] = base;
+    if (a.score_work) {
+        // the set's magnitude bounds: one block owns the set, so they are stored, not merged
+        am = wave_max_u64(am);
+        um = wave_max_u64(um);
+        wm = wave_max_u64(wm);
+        if (lane == 0) {
+            red[0][wave] = am;
+            red[1][wave] = um;
+            red[2][wave] = wm;
+        }
+        __syncthreads();
+        if (tid < 4) {
+            unsigned long long m = 0ull;
+            if (tid < 3) {
+                m = red[tid][0];
+#pragma unroll
+                for (int w = 1; w < 4; ++w)
+                    m = red[tid][w] > m ? red[tid][w] : m;
+            }
+            reinterpret_cast<unsigned long long *>(score_work_hdr(a.score_work, a.n_rec))[SCORE_HDR * blockIdx.x + tid] = m;
+        }
+    }
 }
 
 Mat34 load34(const double *p)
@@ -339,7 +373,24 @@ extern "C" int slam_join_consensus(const int32_t *pair, int n_pairs, int max_nq,
                                    double *cZ, float *cuL, float *cvL, float *cuR, float *cvR, int32_t *count,
                                    void *stream)
 {
+    return slam_join_consensus_prepared(pair, n_pairs, max_nq, t_idx, t_keep, stereo_map, valid3d, X, Y, Z, xL, yL, xR,
+                                        yR, cap, rows, cX, cY, cZ, cuL, cvL, cuR, cvR, count, nullptr, 0.0, nullptr,
+                                        stream);
+}
+
+extern "C" int slam_join_consensus_prepared(const int32_t *pair, int n_pairs, int max_nq, const int32_t *t_idx,
+                                            const uint8_t *t_keep, const int32_t *stereo_map, const uint8_t *valid3d,
+                                            const double *X, const double *Y, const double *Z, const float *xL,
+                                            const float *yL, const float *xR, const float *yR, int cap, int32_t *rows,
+                                            double *cX, double *cY, double *cZ, float *cuL, float *cvL, float *cuR,
+                                            float *cvR, int32_t *count, const double *K, double thresh,
+                                            double *score_work, void *stream)
+{
     (void)max_nq;
+    if (score_work && !K)
+        return fail(SLAM_ERR_BAD_ARG, "slam_join_consensus_prepared: a scoring workspace needs the intrinsics");
+    if (reinterpret_cast<uintptr_t>(score_work) & 15)
+        return fail(SLAM_ERR_BAD_ARG, "slam_join_consensus_prepared: score_work must be 16-byte aligned");
     if (n_pairs < 0 || cap < 0)
         return fail(SLAM_ERR_BAD_ARG, "slam_join_consensus: negative size");
     if (n_pairs == 0)
@@ -372,6 +423,13 @@ extern "C" int slam_join_consensus(const int32_t *pair, int n_pairs, int max_nq,
     a.cuR = cuR;
     a.cvR = cvR;
     a.count = count;
+    a.score_work = score_work;
+    a.n_rec = (size_t)n_pairs * cap;
+    a.fx = K ? K[0] : 0.0;
+    a.fy = K ? K[4] : 0.0;
+    a.cx = K ? K[2] : 0.0;
+    a.cy = K ? K[5] : 0.0;
+    a.thr = thresh;
     hipLaunchKernelGGL(join_kernel, dim3(n_pairs), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("slam_join_consensus");
 }

@@ -33,6 +33,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "score_records.h"
 #include "supports.h"
 
 namespace slam {
@@ -127,33 +128,13 @@ __global__ void __launch_bounds__(256) clear_mask_tail_kernel(unsigned long long
 }
 
 // ---- fast path ---------------------------------------------------------------
-// Workspace layout (in doubles, n_rec = n_sets * cap):
-//   [n_rec][8]            fp64 point records  X Y Z uL vL uR vR pad
-//   [n_rec][4]            fp32 point records (8 floats, threshold units, principal point removed)
-//                            X Y Z (uL-cx)/thr (vL-cy)/thr (uR-cx)/thr (vR-cy)/thr A2
-//                         A2 >= (|X|+|Y|+|Z|)^2, rounded up
-//   [n_rec][8]            bf16 operand records of the matrix-core kernel (32 bf16 = 64 bytes):
-//                            X, Y, Z each split into three 8-bit pieces and laid out as the
-//                            k-slots of the products with a coefficient's three pieces
-//   [n_sets][4]           per-set bounds kept as the bit patterns of non-negative doubles:
-//                         Amax = max(|X|+|Y|+|Z|), Umax = max(|uL|+|vL|+|uR|+|vR|),
-//                         Wmax = max(|u-cx|+|fx|, |v-cy|+|fy|)/thr over both cameras, pad
-constexpr int SCORE_REC = 8;
-constexpr int SCORE_REC32 = 8;   // floats
-constexpr int SCORE_HDR = 4;
-constexpr int SCORE_WORK_PER_REC = SCORE_REC + 4 + 8;   // doubles of workspace per point record
+// (workspace layout: score_records.h)
 constexpr int SCORE_QUEUE = 16;  // undecided points a lane can park before it falls back to fp64 for all
 
-__device__ __forceinline__ double *score_recs64(const ScoreArgs &a) { return a.work; }
-__device__ __forceinline__ float *score_recs32(const ScoreArgs &a)
-{
-    return reinterpret_cast<float *>(a.work + SCORE_REC * a.n_rec);
-}
-__device__ __forceinline__ uint4 *score_recs16(const ScoreArgs &a)
-{
-    return reinterpret_cast<uint4 *>(a.work + (SCORE_REC + 4) * a.n_rec);
-}
-__device__ __forceinline__ double *score_hdr(const ScoreArgs &a) { return a.work + SCORE_WORK_PER_REC * a.n_rec; }
+__device__ __forceinline__ double *score_recs64(const ScoreArgs &a) { return score_work_recs64(a.work); }
+__device__ __forceinline__ float *score_recs32(const ScoreArgs &a) { return score_work_recs32(a.work, a.n_rec); }
+__device__ __forceinline__ uint4 *score_recs16(const ScoreArgs &a) { return score_work_recs16(a.work, a.n_rec); }
+__device__ __forceinline__ double *score_hdr(const ScoreArgs &a) { return score_work_hdr(a.work, a.n_rec); }
 
 // v = p0 + p1 + p2 exactly, each piece a bf16 (8 significant bits, same sign as v): the bf16 bit
 // patterns.  (Pieces below the fp32 denormal range are lost: an absolute error under 2^-126.)
@@ -166,16 +147,6 @@ __device__ __forceinline__ void split3(float v, uint32_t &p0, uint32_t &p1, uint
     p0 = b0 >> 16;
     p1 = b1 >> 16;
     p2 = __float_as_uint(r2) >> 16;
-}
-
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(v, off);
-        v = o > v ? o : v;
-    }
-    return v;
 }
 
 // Widens the point data to fp64 records, writes the fp32 records and reduces the per-set
@@ -195,22 +166,9 @@ __global__ void __launch_bounds__(256) score_prep_kernel(const ScoreArgs a, int 
     unsigned long long am = 0ull, um = 0ull, wm = 0ull;
     if (i < n) {
         const size_t o = (size_t)set * a.cap + i;
-        const double uL = (double)a.uL[o], vL = (double)a.vL[o], uR = (double)a.uR[o], vR = (double)a.vR[o];
         const double X = a.X[o], Y = a.Y[o], Z = a.Z[o];
-        double2 *rec = reinterpret_cast<double2 *>(score_recs64(a) + SCORE_REC * o);
-        rec[0] = make_double2(X, Y);
-        rec[1] = make_double2(Z, uL);
-        rec[2] = make_double2(vL, uR);
-        rec[3] = make_double2(vR, 0.0);
-        const double A = (fabs(X) + fabs(Y)) + fabs(Z);
-        const double U = (fabs(uL) + fabs(vL)) + (fabs(uR) + fabs(vR));
-        const double fx = a.K.m[0], fy = a.K.m[4], cx = a.K.m[2], cy = a.K.m[5], thr = a.thresh;
-        const double ul = (uL - cx) / thr, vl = (vL - cy) / thr, ur = (uR - cx) / thr, vr = (vR - cy) / thr;
-        const double W = fmax(fmax(fabs(ul), fabs(ur)) + fabs(fx / thr), fmax(fabs(vl), fabs(vr)) + fabs(fy / thr));
-        float4 *r32 = reinterpret_cast<float4 *>(score_recs32(a) + SCORE_REC32 * o);
-        // A2 is an upper bound of A^2 after the rounding to fp32
-        r32[0] = make_float4((float)X, (float)Y, (float)Z, (float)ul);
-        r32[1] = make_float4((float)vl, (float)ur, (float)vr, (float)((A * A) * 1.000001));
+        score_write_record(a.work, a.n_rec, o, X, Y, Z, a.uL[o], a.vL[o], a.uR[o], a.vR[o], a.K.m[0], a.K.m[4], a.K.m[2],
+                           a.K.m[5], a.thresh, am, um, wm);
         // k-slot layout of the matrix-core kernel: slots 9t + 3i + j (t = X, Y, Z) pair piece i
         // of a coefficient with piece j of the coordinate; slots 27..29 pair the constant term's
         // pieces with 1.0; slots 30, 31 are unused
@@ -232,9 +190,6 @@ __global__ void __launch_bounds__(256) score_prep_kernel(const ScoreArgs a, int 
                 r16[c] = make_uint4(slot[8 * c] | (slot[8 * c + 1] << 16), slot[8 * c + 2] | (slot[8 * c + 3] << 16),
                                     slot[8 * c + 4] | (slot[8 * c + 5] << 16), slot[8 * c + 6] | (slot[8 * c + 7] << 16));
         }
-        am = (A == A) ? (unsigned long long)__double_as_longlong(A) : ~0ull;
-        um = (U == U) ? (unsigned long long)__double_as_longlong(U) : ~0ull;
-        wm = (W == W) ? (unsigned long long)__double_as_longlong(W) : ~0ull;
     }
     am = wave_max_u64(am);
     um = wave_max_u64(um);
@@ -1058,7 +1013,7 @@ extern "C" int slam_score_hypotheses_range(const double *Rt, int n_sets, int H_t
         const char *impl = getenv("SLAM_SCORE_IMPL");
         const bool f64_only = impl && impl[0] == 'f' && impl[1] == '6';
         const bool use_mfma = impl && impl[0] == 'b';
-        if (!work_ready) {
+        if (!work_ready || use_mfma) {   // (the matrix-core variant has operand records only this pass writes)
             hipError_t e =
                 hipMemsetAsync(work + SCORE_WORK_PER_REC * a.n_rec, 0, sizeof(double) * SCORE_HDR * (size_t)n_sets, s);
             if (e != hipSuccess)

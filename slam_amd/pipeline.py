@@ -209,19 +209,25 @@ class FrontEnd:
 
     def join(self, ws, stream):
         tb, c = ws.tb, ws.cons
-        st = self.lib.slam_join_consensus(_p(ws.pair), ws.P, ws.max_nL, _p(ws.t_idx), _p(ws.t_keep), _p(ws.smap),
-                                          _p(ws.valid), _p(ws.X), _p(ws.Y), _p(ws.Z), _p(tb.xL), _p(tb.yL), _p(tb.xR),
-                                          _p(tb.yR), ws.cap, _p(c.rows), _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL),
-                                          _p(c.vL), _p(c.uR), _p(c.vR), _p(c.count), stream)
-        _lib.check(st, "slam_join_consensus")
+        # the join also lays out the scoring workspace of its consensus sets (unless masks are
+        # wanted: that scoring path reads the plain tables)
+        work = ws.score_work if ws.masks is None else None
+        st = self.lib.slam_join_consensus_prepared(_p(ws.pair), ws.P, ws.max_nL, _p(ws.t_idx), _p(ws.t_keep),
+                                                   _p(ws.smap), _p(ws.valid), _p(ws.X), _p(ws.Y), _p(ws.Z), _p(tb.xL),
+                                                   _p(tb.yL), _p(tb.xR), _p(tb.yR), ws.cap, _p(c.rows), _p(c.X), _p(c.Y),
+                                                   _p(c.Z), _p(c.uL), _p(c.vL), _p(c.uR), _p(c.vR), _p(c.count), ws.hK,
+                                                   self.pix_thresh, _p(work), stream)
+        _lib.check(st, "slam_join_consensus_prepared")
+        ws.work_ready = 1 if work is not None else 0
 
     def score(self, ws, Rt, stream):
         """Rt: [P, H, 3, 4] (or [P,H,12]) float64 on the device."""
         c = ws.cons
-        st = self.lib.slam_score_hypotheses(_p(Rt), ws.P, ws.H, ws.hK, ws.hT, _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL),
-                                            _p(c.vL), _p(c.uR), _p(c.vR), ws.cap, _p(c.count), 0, self.pix_thresh,
-                                            _p(ws.counts), _p(ws.masks), ws.mask_words if ws.masks is not None else 0,
-                                            _p(ws.score_work), stream)
+        st = self.lib.slam_score_hypotheses_range(_p(Rt), ws.P, ws.H, 0, ws.H, None, ws.hK, ws.hT, _p(c.X), _p(c.Y),
+                                                  _p(c.Z), _p(c.uL), _p(c.vL), _p(c.uR), _p(c.vR), ws.cap, _p(c.count),
+                                                  0, self.pix_thresh, _p(ws.counts), _p(ws.masks),
+                                                  ws.mask_words if ws.masks is not None else 0, _p(ws.score_work),
+                                                  getattr(ws, "work_ready", 0), stream)
         _lib.check(st, "slam_score_hypotheses")
 
     def select(self, ws, Rt, stream, dense=True):
@@ -304,7 +310,7 @@ class FrontEnd:
             st = lib.slam_score_hypotheses_range(_p(ws.Rt_gen), ws.P, ws.H, h0, hn, _p(skip), ws.hK, ws.hT, _p(c.X),
                                                  _p(c.Y), _p(c.Z), _p(c.uL), _p(c.vL), _p(c.uR), _p(c.vR), ws.cap,
                                                  _p(c.count), 0, self.pix_thresh, _p(ws.counts), None, 0,
-                                                 _p(ws.score_work), 1 if h0 > 0 else 0, stream)
+                                                 _p(ws.score_work), 1 if h0 > 0 else getattr(ws, "work_ready", 0), stream)
             _lib.check(st, "slam_score_hypotheses_range")
 
         def select(n_avail):

@@ -267,3 +267,35 @@ def test_winner_tables_match_the_mask_path(device):
     assert torch.equal(ws.n_inl, fused["n_inl"])
     assert torch.equal(ws.inl_rows[:total], fused["inl_rows"][:total])
     assert torch.equal(ws.inl_loc[:total], fused["inl_loc"][:total])
+
+
+def test_join_prepares_the_scoring_workspace(device):
+    """The workspace the join fills on the way (slam_join_consensus_prepared) is byte for byte
+    the one the scoring call prepares for itself, and the counts do not depend on who did it."""
+    k, m1, m2 = read_cameras()
+    seq = SyntheticSequence(700, 5, seed=31)
+    f = seq.frames[2]                                    # pairs 1 and 2 end up without consensus matches
+    seq.frames[2] = type(f)(f.kpL[:0], f.kpR[:0], f.descL[:0], f.descR[:0], f.idL[:0], f.idR[:0], f.Rt)
+    P, H = 4, 130
+    Rt = torch.from_numpy(np.stack([seeded_hypotheses(seq.relative_pose(p, p + 1), H, seed=p) for p in range(P)])).to(device)
+    fe = pipeline.FrontEnd(k, m1, m2)
+    tb = pipeline.FrameTables.from_frames(seq.frames, device)
+    ws = fe.prepare(tb, n_hyp=H)
+    stream = torch.cuda.current_stream().cuda_stream
+    fe.stereo_match(ws, stream)
+    fe.triangulate(ws, stream)
+    fe.temporal_match(ws, stream)
+    ws.score_work.zero_()
+    fe.join(ws, stream)
+    assert ws.work_ready == 1
+    by_join = ws.score_work.clone()
+    fe.score(ws, Rt, stream)
+    counts_a = ws.counts.clone()
+    ws.score_work.zero_()
+    ws.work_ready = 0
+    fe.score(ws, Rt, stream)                             # prepares the workspace itself
+    torch.cuda.synchronize()
+    assert torch.equal(by_join.view(torch.int64), ws.score_work.view(torch.int64))
+    assert torch.equal(counts_a, ws.counts)
+    n = ws.cons.count.cpu().numpy()[:P]
+    assert n[0] > 50 and n[1] == 0 and n[2] == 0 and int(counts_a[0].max()) > 0
