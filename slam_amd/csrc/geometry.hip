@@ -224,16 +224,19 @@ struct JoinArgs {
     double fx, fy, cx, cy, thr;
 };
 
-__global__ void __launch_bounds__(256) join_kernel(const JoinArgs a)
+constexpr int JOIN_BLOCK = 1024;   // one block per frame pair: wide, so that a pair is a couple of trips
+constexpr int JOIN_WAVES = JOIN_BLOCK / 64;
+
+__global__ void __launch_bounds__(JOIN_BLOCK) join_kernel(const JoinArgs a)
 {
-    __shared__ int wave_tot[4];
-    __shared__ unsigned long long red[3][4];
+    __shared__ int wave_tot[JOIN_WAVES];
+    __shared__ unsigned long long red[3][JOIN_WAVES];
     unsigned long long am = 0ull, um = 0ull, wm = 0ull;
     const int32_t *pr = a.pair + SLAM_PAIR_STRIDE * blockIdx.x;
     const int p0 = pr[0], pn = pr[1], c0 = pr[2], cn = pr[3], t0 = pr[4], r0 = pr[5];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int base = 0;
-    for (int q0 = 0; q0 < pn; q0 += 256) {
+    for (int q0 = 0; q0 < pn; q0 += JOIN_BLOCK) {
         const int q = q0 + tid;
         bool take = false;
         int t = -1, pr_right = -1, cr_right = -1;
@@ -250,10 +253,12 @@ __global__ void __launch_bounds__(256) join_kernel(const JoinArgs a)
         if (lane == 0)
             wave_tot[wave] = __popcll(m);
         __syncthreads();
-        int off = base;
-        for (int w = 0; w < wave; ++w)
-            off += wave_tot[w];
-        const int total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        int off = base, total = 0;
+#pragma unroll
+        for (int w = 0; w < JOIN_WAVES; ++w) {
+            off += w < wave ? wave_tot[w] : 0;
+            total += wave_tot[w];
+        }
         const int slot = off + before;
         if (take && slot < a.cap) {
             const size_t o = (size_t)blockIdx.x * a.cap + slot;
@@ -292,7 +297,7 @@ __global__ void __launch_bounds__(256) join_kernel(const JoinArgs a)
             if (tid < 3) {
                 m = red[tid][0];
 #pragma unroll
-                for (int w = 1; w < 4; ++w)
+                for (int w = 1; w < JOIN_WAVES; ++w)
                     m = red[tid][w] > m ? red[tid][w] : m;
             }
             reinterpret_cast<unsigned long long *>(score_work_hdr(a.score_work, a.n_rec))[SCORE_HDR * blockIdx.x + tid] = m;
@@ -430,6 +435,6 @@ extern "C" int slam_join_consensus_prepared(const int32_t *pair, int n_pairs, in
     a.cx = K ? K[2] : 0.0;
     a.cy = K ? K[5] : 0.0;
     a.thr = thresh;
-    hipLaunchKernelGGL(join_kernel, dim3(n_pairs), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(join_kernel, dim3(n_pairs), dim3(JOIN_BLOCK), 0, (hipStream_t)stream, a);
     return check_launch("slam_join_consensus");
 }
