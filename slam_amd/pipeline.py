@@ -151,6 +151,7 @@ class FrontEnd:
         ws.masks = (torch.zeros((max(ws.P, 1), max(ws.H, 1), max(ws.mask_words, 1)), dtype=torch.int64, device=dev)
                     if want_masks else None)
         ws.score_work = f64(24 * max(ws.P * ws.cap, 1))
+        ws.work_ready = 0          # 1 once the join has laid out score_work for the current consensus sets
         # winner selection + inlier tables
         np_ = max(ws.P, 1)
         ws.best, ws.best_count = i32(np_), i32(np_)
@@ -227,7 +228,7 @@ class FrontEnd:
                                                   _p(c.Z), _p(c.uL), _p(c.vL), _p(c.uR), _p(c.vR), ws.cap, _p(c.count),
                                                   0, self.pix_thresh, _p(ws.counts), _p(ws.masks),
                                                   ws.mask_words if ws.masks is not None else 0, _p(ws.score_work),
-                                                  getattr(ws, "work_ready", 0), stream)
+                                                  ws.work_ready, stream)
         _lib.check(st, "slam_score_hypotheses")
 
     def select(self, ws, Rt, stream, dense=True):
@@ -310,7 +311,7 @@ class FrontEnd:
             st = lib.slam_score_hypotheses_range(_p(ws.Rt_gen), ws.P, ws.H, h0, hn, _p(skip), ws.hK, ws.hT, _p(c.X),
                                                  _p(c.Y), _p(c.Z), _p(c.uL), _p(c.vL), _p(c.uR), _p(c.vR), ws.cap,
                                                  _p(c.count), 0, self.pix_thresh, _p(ws.counts), None, 0,
-                                                 _p(ws.score_work), 1 if h0 > 0 else getattr(ws, "work_ready", 0), stream)
+                                                 _p(ws.score_work), 1 if h0 > 0 else ws.work_ready, stream)
             _lib.check(st, "slam_score_hypotheses_range")
 
         def select(n_avail):
