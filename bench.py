@@ -145,46 +145,45 @@ def main():
 
     graph = try_capture(ws)
     overlap = os.environ.get("SLAM_BENCH_OVERLAP", "1") != "0"
-    if multi:
-        # Two workspaces take turns so that the gather of step i (side stream, RCCL) overlaps the
-        # kernels of step i+1; a workspace is reused only after its gather has finished.
-        slots = [(ws, graph, sharding.TableGather(ws, world, rank, collective=True))]
-        ws_b = fe.prepare(tb, n_hyp=H, want_masks=False, table_pairs=table_pairs, table_rows=table_rows)
-        slots.append((ws_b, try_capture(ws_b), sharding.TableGather(ws_b, world, rank, collective=True)))
-        side = torch.cuda.Stream()
-        sent = [None, None]
-        step_no = [0]
+    # Batches in flight (SLAM_BENCH_STREAMS, default 2): each has its own workspace, graph and launch
+    # stream, and the steps take turns.  The small latency-bound kernels and the tails of one batch
+    # then run under the large kernels of the other; with more than one rank the gather of step i
+    # (side stream, RCCL) also overlaps the kernels of step i+1.  A workspace is reused only after
+    # its previous step -- and its gather -- has finished.
+    n_lanes = max(1, int(os.environ.get("SLAM_BENCH_STREAMS", "2")))
+    if multi and not overlap:
+        n_lanes = 1
+    lanes = []
+    for i in range(n_lanes):
+        w = ws if i == 0 else fe.prepare(tb, n_hyp=H, want_masks=False, table_pairs=table_pairs, table_rows=table_rows)
+        g = graph if i == 0 else try_capture(w)
+        launch = torch.cuda.current_stream() if n_lanes == 1 else torch.cuda.Stream()
+        gather = sharding.TableGather(w, world, rank, collective=True) if multi else None
+        lanes.append([w, g, launch, gather, None])          # last: event of the lane's last gather
+    side = torch.cuda.Stream() if multi else None
+    step_no = [0]
 
     def step():
-        if not multi:
-            if graph is not None:
-                graph.replay()
-            else:
-                fe.run(ws, Rt)
-            return
-        if not overlap:                                # gather on the launch stream, right after the kernels
-            w, g, gather = slots[0]
+        lane = lanes[step_no[0] % n_lanes]
+        step_no[0] += 1
+        w, g, launch, gather, sent = lane
+        with torch.cuda.stream(launch):
+            if sent is not None:
+                launch.wait_event(sent)
             if g is not None:
                 g.replay()
             else:
                 fe.run(w, Rt)
-            gather.run()
-            return
-        b = step_no[0] & 1
-        step_no[0] += 1
-        w, g, gather = slots[b]
-        main = torch.cuda.current_stream()
-        if sent[b] is not None:
-            main.wait_event(sent[b])
-        if g is not None:
-            g.replay()
-        else:
-            fe.run(w, Rt)
-        ready = main.record_event()
+            if gather is None:
+                return
+            if not overlap:                            # gather on the launch stream, right after the kernels
+                gather.run()
+                return
+            ready = launch.record_event()
         with torch.cuda.stream(side):
             side.wait_event(ready)
             gather.run()
-            sent[b] = side.record_event()
+            lane[4] = side.record_event()
 
     def fence():
         torch.cuda.synchronize()
@@ -403,6 +402,8 @@ def main():
                 "unit": "GB/s", "frac": tri_gbs / HBM_PEAK_GBS, "traffic": traffic.get("dlt_matched_kernel_bytes_per_launch"),
                 "avg_launch_ms": stage_ms["triangulate"], "algorithmic": f"41 B per point x {n_tri:.4g} points"}
     dominant = score_roof if stage_ms["score"] >= match_ms else match_roof
+    dominant = dict(dominant, timing="HIP events around the kernel running alone on its launch stream, after the timed "
+                                     "region (profiles/: the same with SLAM_BENCH_STREAMS=1, one batch in flight)")
 
     out = {
         "metric": "stereo frame-pairs/sec (match+triangulate+RANSAC)",
@@ -422,6 +423,7 @@ def main():
                    "descriptor_bytes": tb.desc_bytes, "hypotheses_per_pair": H,
                    "mean_consensus_matches": float(n_cons.mean()), "sharding": f"frame-range x{world}",
                    "launch": "hip graph replay" if graph is not None else "plain launches",
+                   "batches_in_flight": n_lanes,
                    "gather": "none" if world == 1 else "one fixed-size RCCL gather of the table arena per step, "
                                                         "overlapped with the next step's kernels"},
         "roofline": dominant,
