@@ -239,7 +239,24 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
+        # the same with two batches in flight (plain launches on two streams, taking turns)
+        ws_r2 = fe.prepare(tb, n_hyp=Hr)
+        fe.prepare_ransac(ws_r2)
+        rl = [(ws_r, torch.cuda.Stream()), (ws_r2, torch.cuda.Stream())]
+        def ransac_turns(n):
+            for i in range(n):
+                w, st = rl[i & 1]
+                with torch.cuda.stream(st):
+                    fe.run_ransac(w, 6)
+        ransac_turns(2)
+        torch.cuda.synchronize()
+        t0r = time.perf_counter()
+        ransac_turns(20)
+        torch.cuda.synchronize()
+        ms2 = (time.perf_counter() - t0r) / 20 * 1e3
+        del ws_r2
         ransac_info = {"hypotheses_per_pair": Hr, "ms_per_step": ms, "frame_pairs_per_s": P / (ms * 1e-3),
+                       "two_batches_in_flight": {"ms_per_step": ms2, "frame_pairs_per_s": P / (ms2 * 1e-3)},
                        "mean_iterations_until_stop": float(ws_r.iters[:P].float().mean().item()),
                        "mean_inlier_ratio": float(ws_r.ratio[:P].mean().item()),
                        "note": "whole front-end incl. device-side minimal samples, P3P, stopping rule and LM "
