@@ -11,6 +11,7 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 static PyObject *loc_triple(const float *l)
 {
@@ -63,6 +64,9 @@ static PyObject *replay_pairs(PyObject *Py_UNUSED(self), PyObject *args)
                           &min_len, &num_frames))
         return NULL;
     PyObject *result = NULL;
+    PyObject **kp_obj = NULL, **slot_tid = NULL, **slot_list = NULL;
+    Py_ssize_t *slot_pair = NULL;
+    int32_t maxkp_done = -1;
     const int32_t *rows = (const int32_t *)rows_b.buf;
     const float *loc = (const float *)loc_b.buf;
     const int64_t *n_inl = (const int64_t *)n_b.buf;
@@ -81,14 +85,44 @@ static PyObject *replay_pairs(PyObject *Py_UNUSED(self), PyObject *args)
         goto done;
     }
 
+    /* Keypoint indices are small: their int objects are made once and shared by every tuple and
+     * dict key that needs them, and "which track did keypoint k of the previous pair's later frame
+     * join" is answered from two arrays (one per frame parity) instead of the Python dicts.  Only
+     * the dicts that outlive the call are filled: last_insertions keeps just the last two pairs. */
+    int32_t maxkp = -1;
+    for (Py_ssize_t i = 0; i < total; ++i) {
+        const int32_t a = rows[4 * i], c = rows[4 * i + 2];
+        if (a < 0 || c < 0) {
+            PyErr_SetString(PyExc_ValueError, "replay_pairs: negative keypoint index");
+            goto done;
+        }
+        if (a > maxkp)
+            maxkp = a;
+        if (c > maxkp)
+            maxkp = c;
+    }
+    const size_t nkp = (size_t)(maxkp + 1);
+    maxkp_done = maxkp;
+    kp_obj = (PyObject **)calloc(nkp ? nkp : 1, sizeof(PyObject *));
+    slot_tid = (PyObject **)calloc(2 * (nkp ? nkp : 1), sizeof(PyObject *));
+    slot_list = (PyObject **)calloc(2 * (nkp ? nkp : 1), sizeof(PyObject *));
+    slot_pair = (Py_ssize_t *)malloc(2 * (nkp ? nkp : 1) * sizeof(Py_ssize_t));
+    if (!kp_obj || !slot_tid || !slot_list || !slot_pair) {
+        PyErr_NoMemory();
+        goto done;
+    }
+    for (size_t i = 0; i < 2 * nkp; ++i)
+        slot_pair[i] = -1;
+
     Py_ssize_t off = 0;
     for (Py_ssize_t p = 0; p < P; ++p) {
         const long frame = first_frame + (long)p;
+        const int keep_dict = p >= P - 2;      /* this pair's keypoint -> track dict survives the call */
         PyObject *f_cur = PyLong_FromLong(frame), *f_nxt = PyLong_FromLong(frame + 1);
         PyObject *par_prev = PyLong_FromLong(frame % 2 < 0 ? frame % 2 + 2 : frame % 2);
         PyObject *par_cur = PyLong_FromLong((frame + 1) % 2 < 0 ? (frame + 1) % 2 + 2 : (frame + 1) % 2);
-        PyObject *in_cur = PySet_New(NULL), *last_cur = PyDict_New();
-        int ok = f_cur && f_nxt && par_prev && par_cur && in_cur && last_cur;
+        PyObject *in_cur = PySet_New(NULL), *last_cur = keep_dict ? PyDict_New() : NULL;
+        int ok = f_cur && f_nxt && par_prev && par_cur && in_cur && (last_cur || !keep_dict);
         PyObject *in_prev = NULL, *last_prev = NULL;
         if (ok) {
             /* prepare_to_next_pair */
@@ -101,8 +135,8 @@ static PyObject *replay_pairs(PyObject *Py_UNUSED(self), PyObject *args)
             } else if (!in_prev) {
                 ok = 0;
             }
-            ok = ok && PyDict_SetItem(frame_ids, f_nxt, in_cur) == 0 && PyDict_SetItem(last_ins, par_cur, last_cur) == 0;
-            if (ok) {
+            ok = ok && PyDict_SetItem(frame_ids, f_nxt, in_cur) == 0;
+            if (ok && p == 0) {
                 last_prev = PyDict_GetItemWithError(last_ins, par_prev);     /* borrowed */
                 if (!last_prev) {
                     if (!PyErr_Occurred())
@@ -110,58 +144,70 @@ static PyObject *replay_pairs(PyObject *Py_UNUSED(self), PyObject *args)
                     ok = 0;
                 }
             }
+            if (ok && keep_dict)
+                ok = PyDict_SetItem(last_ins, par_cur, last_cur) == 0;
         }
+        const size_t cur_slot = (size_t)(p & 1) * nkp, prev_slot = (size_t)((p & 1) ^ 1) * nkp;
         const Py_ssize_t m = (Py_ssize_t)n_inl[p];
         for (Py_ssize_t i = 0; ok && i < m; ++i) {
             const int32_t *r = rows + 4 * (off + i);
             const float *l = loc + 6 * (off + i);
-            PyObject *kp_prev = PyLong_FromLong(r[0]), *kp_cur = PyLong_FromLong(r[2]);
-            PyObject *tid = NULL, *point = NULL;
+            const int32_t a = r[0], c = r[2];
+            if (!kp_obj[a])
+                kp_obj[a] = PyLong_FromLong(a);
+            if (!kp_obj[c])
+                kp_obj[c] = PyLong_FromLong(c);
+            PyObject *kp_prev = kp_obj[a], *kp_cur = kp_obj[c];              /* owned by kp_obj[] */
+            PyObject *tid = NULL, *track = NULL;                            /* borrowed (the track dict owns both) */
             ok = kp_prev && kp_cur;
-            if (ok) {
-                tid = PyDict_GetItemWithError(last_prev, kp_prev);           /* borrowed */
-                if (tid) {
-                    Py_INCREF(tid);
-                } else if (PyErr_Occurred()) {
+            if (ok && p > 0) {
+                if (slot_pair[prev_slot + (size_t)a] == p - 1) {
+                    tid = slot_tid[prev_slot + (size_t)a];
+                    track = slot_list[prev_slot + (size_t)a];
+                }
+            } else if (ok) {
+                tid = PyDict_GetItemWithError(last_prev, kp_prev);
+                if (!tid && PyErr_Occurred())
                     ok = 0;
-                } else {
-                    tid = PyLong_FromLong(next_free++);
-                    ok = tid != NULL;
+                if (ok && tid) {
+                    track = PyDict_GetItemWithError(tracks, tid);
+                    if (!track && PyErr_Occurred())
+                        ok = 0;
                 }
             }
-            PyObject *track = NULL;
-            if (ok) {
-                track = PyDict_GetItemWithError(tracks, tid);                /* borrowed */
-                if (!track && PyErr_Occurred())
-                    ok = 0;
-            }
             if (ok && !track) {
+                PyObject *new_tid = NULL;
+                if (!tid) {
+                    new_tid = PyLong_FromLong(next_free++);
+                    tid = new_tid;
+                }
                 PyObject *lst = PyList_New(0);
-                PyObject *first = lst ? track_point(kp_prev, l, f_cur) : NULL;
+                PyObject *first = (lst && tid) ? track_point(kp_prev, l, f_cur) : NULL;
                 ok = lst && first && PyList_Append(lst, first) == 0 && PyDict_SetItem(tracks, tid, lst) == 0 &&
                      PySet_Add(in_prev, tid) == 0;
                 track = lst;                                                 /* kept alive by the dict */
                 Py_XDECREF(first);
                 Py_XDECREF(lst);
+                Py_XDECREF(new_tid);                                         /* likewise, as its key */
                 if (ok)
                     ++num_tracks;
             }
             if (ok) {
-                point = track_point(kp_cur, l + 3, f_nxt);
+                PyObject *point = track_point(kp_cur, l + 3, f_nxt);
                 ok = point && PyList_Append(track, point) == 0 && PySet_Add(in_cur, tid) == 0 &&
-                     PyDict_SetItem(last_cur, kp_cur, tid) == 0;
+                     (!keep_dict || PyDict_SetItem(last_cur, kp_cur, tid) == 0);
+                Py_XDECREF(point);
             }
             if (ok) {
+                slot_pair[cur_slot + (size_t)c] = p;
+                slot_tid[cur_slot + (size_t)c] = tid;
+                slot_list[cur_slot + (size_t)c] = track;
                 const long n = (long)PyList_GET_SIZE(track);
                 if (n > max_len)
                     max_len = n;
                 if (min_len < 0 || n < min_len)
                     min_len = n;
             }
-            Py_XDECREF(point);
-            Py_XDECREF(tid);
-            Py_XDECREF(kp_prev);
-            Py_XDECREF(kp_cur);
         }
         Py_XDECREF(f_cur);
         Py_XDECREF(f_nxt);
@@ -177,6 +223,13 @@ static PyObject *replay_pairs(PyObject *Py_UNUSED(self), PyObject *args)
     }
     result = Py_BuildValue("lllll", next_free, num_tracks, max_len, min_len, num_frames);
 done:
+    if (kp_obj)
+        for (int32_t i = 0; i <= maxkp_done; ++i)
+            Py_XDECREF(kp_obj[i]);
+    free(kp_obj);
+    free(slot_tid);
+    free(slot_list);
+    free(slot_pair);
     PyBuffer_Release(&rows_b);
     PyBuffer_Release(&loc_b);
     PyBuffer_Release(&n_b);
