@@ -101,7 +101,7 @@ class TrackDatabase:
             (pl, pr), (cl, cr) = arrays(frameId), arrays(frameId + 1)
             loc = np.stack([pl[rows[:, 0], 0], pr[rows[:, 1], 0], pl[rows[:, 0], 1],
                             cl[rows[:, 2], 0], cr[rows[:, 3], 0], cl[rows[:, 2], 1]], axis=1)
-            self.update_tracks_from_tables(frameId, rows, loc)
+            self.update_tracks_from_pair_tables(frameId, rows, loc, [rows.shape[0]])
             return
         self.prepare_to_next_pair(frameId)
         for prev_left, prev_right, cur_left, cur_right, _ in matches_kp_indices_and_3d_points:
