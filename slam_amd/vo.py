@@ -48,7 +48,7 @@ def track_camera_batched(frames, cameras=None, thresh=1, max_iterations=VO_MAX_I
         loc = np.stack([f0.kpL[rows[:, 0], 0], f0.kpR[rows[:, 1], 0], f0.kpL[rows[:, 0], 1],
                         f1.kpL[rows[:, 2], 0], f1.kpR[rows[:, 3], 0], f1.kpL[rows[:, 2], 1]], axis=1) \
             if len(sel) else np.zeros((0, 6), np.float32)
-        db.update_tracks_from_tables(p, rows, loc)
+        db.update_tracks_from_pair_tables(p, rows, loc, [len(rows)])
         db.add_inliers_ratio(p, ratio)
         db.add_num_matches(p, num_matches=np.sum(mask))
         rel.append(Rt)
