@@ -117,3 +117,25 @@ def test_frame_update_through_tables_equals_the_row_loop():
     assert a == b and a.get_num_tracks() > 0
     t = next(iter(a._tracks.values()))
     assert type(t[0][0]) is int and all(type(v) is float for v in t[0][1])
+
+
+def test_keypoint_containers_remember_their_coordinates():
+    """Lists / object arrays made from a coordinate array hand that array back instead of walking
+    the KeyPoint objects; slices, copies and pickles fall back to the objects and agree."""
+    import pickle
+
+    from slam_amd import types
+
+    xy = np.random.default_rng(0).uniform(0, 1200, (50, 2)).astype(np.float32)
+    kps = types.keypoints_from_array(xy)
+    assert isinstance(kps, list) and types.keypoints_to_array(kps) is kps.array
+    assert kps[7].pt == (float(xy[7, 0]), float(xy[7, 1]))
+    arr = types.keypoint_object_array(kps)
+    assert arr.dtype == object and arr.shape == (50,) and arr[7] is kps[7]
+    assert types.keypoints_to_array(arr) is kps.array
+    for other in (arr[:10], arr.copy()[::2], pickle.loads(pickle.dumps(arr)), list(kps)[:10], kps + kps[:1]):
+        got = types.keypoints_to_array(other)
+        assert got is not kps.array and got.dtype == np.float32
+        assert np.array_equal(got, np.array([k.pt for k in other], dtype=np.float32).reshape(-1, 2))
+    kps.append(types.KeyPoint(1.0, 2.0))                    # a list that grew no longer matches its array
+    assert types.keypoints_to_array(kps).shape == (51, 2)
