@@ -85,7 +85,8 @@ def p3p_4pt(points_3d, points_2d, K):
     points_2d = np.asarray(points_2d, dtype=np.float64).reshape(-1, 2)
     if points_3d.shape[0] < 4:
         return None
-    Kinv = np.linalg.inv(np.asarray(K, dtype=np.float64))
+    K = np.asarray(K, dtype=np.float64)
+    Kinv = np.linalg.inv(K)
     rays = (Kinv @ np.hstack([points_2d, np.ones((points_2d.shape[0], 1))]).T).T
     f = rays / np.linalg.norm(rays, axis=1, keepdims=True)
     sols = p3p_grunert(points_3d[:3], f[:3])
@@ -99,8 +100,12 @@ def p3p_4pt(points_3d, points_2d, K):
             best, best_err = np.hstack([R, t[:, None]]), err
     if best is not None:
         # The quartic loses digits on thin triangles; a few Gauss-Newton steps on the three
-        # defining points (6 equations, 6 unknowns) restore an exact fit to them.
-        polished = refine_pnp(points_3d[:3], points_2d[:3], K, best, iterations=4)
+        # defining points (6 equations, 6 unknowns) restore an exact fit to them.  Most samples
+        # fit their three points to rounding already and are left as they are.
+        Y3 = points_3d[:3] @ best[:, :3].T + best[:, 3]
+        fit = np.abs(np.stack([K[0, 0] * Y3[:, 0] / Y3[:, 2] + K[0, 2], K[1, 1] * Y3[:, 1] / Y3[:, 2] + K[1, 2]],
+                              axis=1) - points_2d[:3]).max()
+        polished = refine_pnp(points_3d[:3], points_2d[:3], K, best, iterations=4) if not fit < 1e-9 else None
         if polished is not None:
             x = K @ (polished[:, :3] @ points_3d[3] + polished[:, 3])
             if x[2] > 0 and np.linalg.norm(x[:2] / x[2] - points_2d[3]) <= best_err + 1e-6:
