@@ -299,3 +299,55 @@ def test_join_prepares_the_scoring_workspace(device):
     assert torch.equal(counts_a, ws.counts)
     n = ws.cons.count.cpu().numpy()[:P]
     assert n[0] > 50 and n[1] == 0 and n[2] == 0 and int(counts_a[0].max()) > 0
+
+
+def test_two_batches_in_flight_on_two_streams(device):
+    """The library keeps no state between calls: two workspaces driven from two streams at the
+    same time (as bench.py does) give what each gives alone, for the given-hypotheses path and
+    for the device-side RANSAC."""
+    k, m1, m2 = read_cameras()
+    seqs = [SyntheticSequence(900, 6, seed=41), SyntheticSequence(700, 6, seed=42)]
+    P, H = 5, 600
+    fe = pipeline.FrontEnd(k, m1, m2)
+    lanes = []
+    for s_, seq in enumerate(seqs):
+        tb = pipeline.FrameTables.from_frames(seq.frames, device)
+        ws = fe.prepare(tb, n_hyp=H)
+        fe.prepare_ransac(ws)
+        Rt = torch.from_numpy(np.stack([seeded_hypotheses(seq.relative_pose(p, p + 1), H, seed=7 * s_ + p)
+                                        for p in range(P)])).to(device)
+        lanes.append((ws, Rt, torch.cuda.Stream()))
+    names = ("counts", "best", "n_inl", "inl_rows", "inl_loc")
+    rnames = ("iters", "best_count", "n_inl", "inl_rows", "pose")
+
+    def snap(ws, which):
+        return {n: getattr(ws, n).clone() for n in which}
+
+    alone, alone_r = [], []
+    for ws, Rt, _ in lanes:
+        fe.run(ws, Rt)
+        torch.cuda.synchronize()
+        alone.append(snap(ws, names))
+        fe.run_ransac(ws, seed=9)
+        torch.cuda.synchronize()
+        alone_r.append(snap(ws, rnames))
+    for mode, want, which in (("run", alone, names), ("ransac", alone_r, rnames)):
+        for ws, _, _ in lanes:
+            for n in which:
+                getattr(ws, n).zero_()
+        torch.cuda.synchronize()
+        for _ in range(3):                                  # several rounds, the streams free to overlap
+            for ws, Rt, st in lanes:
+                with torch.cuda.stream(st):
+                    if mode == "run":
+                        fe.run(ws, Rt)
+                    else:
+                        fe.run_ransac(ws, seed=9)
+        torch.cuda.synchronize()
+        for (ws, _, _), ref in zip(lanes, want):
+            total = int(ref["n_inl"].sum())
+            for n in which:
+                a, b = ref[n], getattr(ws, n)
+                if n.startswith("inl_"):
+                    a, b = a[:total], b[:total]
+                assert np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True), (mode, n)
