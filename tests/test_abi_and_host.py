@@ -52,6 +52,29 @@ def test_argument_validation_needs_no_gpu():
     assert lib.slam_triangulate_dlt(null, null, null, null, null, null, 5, null, null, null, null, null) == -1
     assert lib.slam_score_hypotheses(null, 1, 1, null, null, null, null, null, null, null, null, null, 4, null, 4,
                                      2.0, null, null, 0, null, null) == -1
+    # the fused entry points of the batched path
+    K9 = (ctypes.c_double * 9)(700.0, 0.0, 600.0, 0.0, 700.0, 180.0, 0.0, 0.0, 1.0)
+    t3 = (ctypes.c_double * 3)(-0.5, 0.0, 0.0)
+    assert lib.slam_winner_tables(*([null, 3, null, null, 16, K9, t3, 2.0] + [null] * 16)) == -1
+    assert b"null" in lib.slam_last_error()
+    assert lib.slam_winner_tables(*([null, -1, null, null, 16, K9, t3, 2.0] + [null] * 16)) == -1
+    assert lib.slam_winner_tables(*([null, 0, null, null, 16, K9, t3, 2.0] + [null] * 16)) == 0
+    refine = [K9, t3, 2.0] + [null] * 7 + [16, null, 16, null, 2, 30, null, null, null, null]
+    assert lib.slam_refine_winners(*refine) == -1 and b"null" in lib.slam_last_error()
+    refine[14] = 0                                              # no sets: nothing to do
+    assert lib.slam_refine_winners(*refine) == 0
+    bad_K = (ctypes.c_double * 9)(700.0, 0.1, 600.0, 0.0, 700.0, 180.0, 0.0, 0.0, 1.0)
+    assert lib.slam_refine_poses(bad_K, null, null, null, null, null, 16, null, 16, ctypes.c_void_p(4096), 1, null, 2,
+                                 30, null, null, null) == -1 and b"pinhole" in lib.slam_last_error()
+    join = [null, 2, 100] + [null] * 11 + [16] + [null] * 9
+    assert lib.slam_join_consensus_prepared(*(join + [null, 2.0, ctypes.c_void_p(4096), null])) == -1
+    assert b"intrinsics" in lib.slam_last_error()               # a workspace without the camera
+    assert lib.slam_join_consensus_prepared(*(join + [K9, 2.0, ctypes.c_void_p(4104), null])) == -1
+    assert b"aligned" in lib.slam_last_error()
+    assert lib.slam_join_consensus_prepared(*(join + [K9, 2.0, null, null])) == -1     # null tables
+    assert lib.slam_score_hypotheses_range(null, 1, 8, 4, 8, null, K9, t3, *([null] * 7), 4, null, 4, 2.0, null, null,
+                                           0, null, 0, null) == -1
+    assert b"exceeds" in lib.slam_last_error()
     # empty work is a no-op success
     assert lib.slam_hamming_match(null, null, null, 0, 0, 0, 61, 64, 2, 0, 0.0, null, null, null, null, null,
                                   null) == 0
