@@ -391,29 +391,44 @@ def main():
         "algorithmic": f"{match_pairs:.4g} descriptor pairs per step x "
                        + (f"{2 * words} int32 ops" if valu_impl else f"{2 * 8 * tb.desc_bytes} matrix-core ops (8*D MACs)"),
     }
-    score_tf = 72.0 * score_evals / (stage_ms["score"] * 1e-3) / 1e12
+    # Scoring: the roofline figure is EXECUTED work -- VALU lane-instructions issued (ISA count of the
+    # kernel's evaluation loop x evaluations) against the chip's VALU issue rate.  The reference's own
+    # arithmetic (72 fp64 flop per evaluation, utils/utils.py:394-404) is kept beside it as a labelled
+    # equivalent: the kernel decides almost every evaluation with far fewer, cheaper operations, so that
+    # figure is an algorithmic speed-up, not a fraction of a hardware roof.
+    score_s = stage_ms["score"] * 1e-3
+    score_tf = 72.0 * score_evals / score_s / 1e12
     f64_only = os.environ.get("SLAM_SCORE_IMPL", "mixed").startswith("f6")
-    score_peak = FP64_VALU_PEAK_TF if f64_only else FP32_VALU_PEAK_TF
     score_name = "score_fast_kernel" if f64_only else "score_mixed_kernel"
-    score_roof = {
-        "kernel": f"{score_name} (1 launch per step)", "bound": "valu-fp64" if f64_only else "valu-fp32",
-        "achieved": score_tf, "peak": score_peak,
-        "unit": "TFLOP/s (reference fp64 flops; " + ("fp64 filter" if f64_only else
-                "decided in fp32, undecided ~2e-4 of the evaluations settled in fp64") + ")",
-        "frac": score_tf / score_peak,
+    if f64_only:
+        score_roof = {
+            "kernel": f"{score_name} (1 launch per step)", "bound": "valu-fp64", "achieved": score_tf,
+            "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s (reference fp64 flops, fp64 filter)",
+            "frac": score_tf / FP64_VALU_PEAK_TF}
+    else:
+        issue = SCORE_MIXED_VALU_PER_EVAL * score_evals / score_s / 1e12
+        score_roof = {
+            "kernel": f"{score_name} (1 launch per step)", "bound": "valu-issue", "achieved": issue,
+            "peak": VALU_ISSUE_PEAK_TOPS,
+            "unit": "T VALU lane-instr/s (executed: 26 instructions per evaluation, ISA count; peak = 256 CU x 4 SIMD "
+                    "x 32 lanes x 2.4 GHz)",
+            "frac": issue / VALU_ISSUE_PEAK_TOPS,
+            "instructions_per_evaluation": SCORE_MIXED_VALU_PER_EVAL,
+            "measured_v_fma_f32_peak": VALU_FMA32_MEASURED_TOPS,
+            "measured_rate_of_this_instruction_mix": SCORE_MIX_MEASURED_TOPS,
+            "frac_of_measured_mix_rate": issue / SCORE_MIX_MEASURED_TOPS}
+    score_roof.update({
         "traffic": traffic.get(f"{score_name}_bytes_per_launch"), "avg_launch_ms": stage_ms["score"],
-        "evaluations_per_s": score_evals / (stage_ms["score"] * 1e-3),
-        "hbm_GBs_algorithmic": score_bytes / (stage_ms["score"] * 1e-3) / 1e9,
-        "algorithmic": f"72 flop per (hypothesis, match) evaluation as the reference writes it "
-                       f"x {score_evals:.4g} evaluations per step",
-    }
-    if not f64_only:
-        issue = SCORE_MIXED_VALU_PER_EVAL * score_evals / (stage_ms["score"] * 1e-3) / 1e12
-        score_roof["valu_issue"] = {"instructions_per_evaluation": SCORE_MIXED_VALU_PER_EVAL, "achieved": issue,
-                                    "peak": VALU_ISSUE_PEAK_TOPS, "unit": "T lane-instr/s",
-                                    "frac": issue / VALU_ISSUE_PEAK_TOPS,
-                                    "measured_v_fma_f32_peak": VALU_FMA32_MEASURED_TOPS,
-                                    "measured_rate_of_this_instruction_mix": SCORE_MIX_MEASURED_TOPS}
+        "evaluations_per_s": score_evals / score_s,
+        "hbm_GBs_algorithmic": score_bytes / score_s / 1e9,
+        "algorithmic": f"{score_evals:.4g} (hypothesis, match) evaluations per step; {score_bytes:.4g} B of poses and "
+                       f"points (100 H + 40 N per set)",
+        "reference_flop_equivalent": {
+            "achieved": score_tf, "unit": "TFLOP/s of the reference's 72 fp64 flop per evaluation",
+            "vs_fp64_valu_peak": score_tf / FP64_VALU_PEAK_TF, "vs_fp32_valu_peak": score_tf / FP32_VALU_PEAK_TF,
+            "note": "an algorithmic speed-up over evaluating the reference's formula, not a roofline fraction: "
+                    "almost every evaluation is decided by a 26-instruction fp32 test, ~2e-4 of them settled in fp64"},
+    })
     tri_gbs = tri_bytes / (stage_ms["triangulate"] * 1e-3) / 1e9
     tri_roof = {"kernel": "dlt_matched_kernel", "bound": "hbm", "achieved": tri_gbs, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": tri_gbs / HBM_PEAK_GBS, "traffic": traffic.get("dlt_matched_kernel_bytes_per_launch"),

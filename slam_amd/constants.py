@@ -5,6 +5,8 @@ The matcher-cache keys and status codes are the integers the reference's callers
 entries and select an image in get_feature_location_frame, MATCHES / CONSECUTIVE /
 FRAMES and the string "FILTERED_MATCHES" (models/Matcher.py:10) key the cache dict.
 """
+import os
+
 KPS = 0
 DSC = 2
 HORIZONTAL_REPRESENTATION = 0
@@ -28,3 +30,8 @@ PIXEL_THRESH = 2
 VO_MAX_ITERATIONS = 1000
 LC_MAX_ITERATIONS = 500
 LC_MIN_CONSENSUS = 10
+
+# dataset location the reference hard-codes (utils/utils.py:16-21)
+SEP = "\\" if os.name == 'nt' else "/"
+DATA_PATH = "VAN_ex/dataset/sequences/05\\" if os.name == 'nt' else "VAN_ex/dataset/sequences/05/"
+GT_PATH = "VAN_ex/dataset/poses/05.txt"

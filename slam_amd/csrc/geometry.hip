@@ -428,7 +428,9 @@ extern "C" int slam_join_consensus_prepared(const int32_t *pair, int n_pairs, in
     a.cuR = cuR;
     a.cvR = cvR;
     a.count = count;
-    a.score_work = score_work;
+    // with no slot per pair there are no records to lay out, and the scoring call does not use
+    // the workspace either (cap == 0 takes its plain path)
+    a.score_work = cap > 0 ? score_work : nullptr;
     a.n_rec = (size_t)n_pairs * cap;
     a.fx = K ? K[0] : 0.0;
     a.fy = K ? K[4] : 0.0;

@@ -18,7 +18,7 @@ import torch
 
 from . import ops
 from .constants import (CONSECUTIVE, FILTERED_MATCHES, FRAMES, HORIZONTAL_REPRESENTATION, LEFT, MATCHES, RIGHT)
-from .types import DMatch, keypoint_object_array, keypoints_from_array, keypoints_to_array
+from .types import DMatch, KeyPoint, keypoint_object_array, keypoints_from_array, keypoints_to_array
 
 
 def _default_device():
@@ -129,6 +129,51 @@ class PrecomputedFeatures:
         return keypoints, self.detectAndCompute(image)[1]
 
 
+_defaults = {"algo": None, "image_reader": None}
+
+
+def set_default_features(algo=None, image_reader=None):
+    """What a bare `Matcher()` uses for detection and images, process-wide: callers that construct
+    the matcher themselves with no arguments (models/TrajectorySolver.py:15, utils/utils.py:240)
+    are pointed at a feature source this way, e.g. set_default_features(PrecomputedFeatures(frames)).
+    None restores the built-in default (cv2's SIFT and the reference's image files when cv2 is
+    installed)."""
+    _defaults["algo"], _defaults["image_reader"] = algo, image_reader
+
+
+def _default_detector():
+    if _defaults["algo"] is not None:
+        return _defaults["algo"]
+    try:
+        import cv2
+    except ImportError:
+        return None                 # detect()/compute() then raise with the message of _need_algo
+    return cv2.SIFT_create()
+
+
+def _default_image_reader():
+    """utils.utils.read_images (utils/utils.py:16-35): KITTI grey images by index through cv2."""
+    if _defaults["image_reader"] is not None:
+        return _defaults["image_reader"]
+    if _defaults["algo"] is not None and hasattr(_defaults["algo"], "read_images"):
+        return _defaults["algo"].read_images
+    try:
+        import cv2
+    except ImportError:
+        return _no_images
+    import os
+    from .constants import DATA_PATH, SEP
+
+    def read(idx):
+        name = '{:06d}.png'.format(idx)
+        img1 = cv2.imread(DATA_PATH + f'image_0{SEP}' + name, 0)
+        img2 = cv2.imread(DATA_PATH + f'image_1{SEP}' + name, 0)
+        if img1 is None or img2 is None:
+            raise FileNotFoundError(f"frame {idx} is not under {os.path.abspath(DATA_PATH)}")
+        return img1, img2
+    return read
+
+
 def _no_images(idx):
     raise FileNotFoundError(
         "no image source: pass image_reader= (a function idx -> (left, right) images) or an algo= with "
@@ -143,11 +188,13 @@ class Matcher:
         self.cache = {}
         self.display = display
         self._file_index = file_index
+        if algo is None:
+            algo = _default_detector()      # cv2.SIFT_create() as models/Matcher.py:15, when cv2 is installed
         self.algo = algo
         self.matcher = matcher if matcher is not None else HipBFMatcher()
         self.threshold = threshold
         if image_reader is None:
-            image_reader = getattr(algo, "read_images", None) or _no_images
+            image_reader = getattr(algo, "read_images", None) or _default_image_reader()
         self._image_reader = image_reader
         self._img1, self._img2 = None, None
         self._filtered_matches = None
@@ -215,7 +262,27 @@ class Matcher:
         return self.cache
 
     def set_cache(self, matcher_cache):
+        """Adopt a cache dict (models/Matcher.py:226-227).  Device-side copies of the previous
+        cache's descriptors are dropped, and entries in the serialised form of
+        get_matcher_cache (keypoints / matches as plain dicts, models/Matcher.py:262-274) are
+        turned back into objects with .pt / .queryIdx so that matching and
+        get_feature_location_frame work on the adopted cache."""
         self.cache = matcher_cache
+        self._packed = {}
+        self._stereo_keep = {}
+        self._synced_frame = None
+        for entry in self.cache.values():
+            if not isinstance(entry, dict):
+                continue
+            for side in (LEFT, RIGHT):
+                if entry.get(side) is not None:
+                    kps, dsc = entry[side]
+                    if len(kps) and isinstance(kps[0], dict):
+                        entry[side] = (_as_object_array([_keypoint_from_dict(k) for k in kps]), dsc)
+            for key in (MATCHES, FILTERED_MATCHES):
+                ms = entry.get(key)
+                if ms is not None and len(ms) and isinstance(ms[0], dict):
+                    entry[key] = [[DMatch(m['queryIdx'], m['trainIdx'], m['distance'])] for m in ms]
 
     # -- detection (delegated to algo) ------------------------------------------
     def _need_algo(self):
@@ -279,11 +346,18 @@ class Matcher:
                           **kw)
         res = self.matcher.knnMatch(q_dsc, t_dsc, k=k)
         idx = np.full((len(res), 2), -1, np.int32)
-        dist = np.full((len(res), 2), np.iinfo(np.int32).max, np.int32)
+        dist = np.full((len(res), 2), np.inf, np.float64)
         for i, row in enumerate(res):
             for c, m in enumerate(row[:2]):
-                idx[i, c], dist[i, c] = m.trainIdx, int(m.distance)
-        return idx, dist, None
+                idx[i, c], dist[i, c] = m.trainIdx, m.distance
+        found = idx >= 0
+        if (dist[found] == np.floor(dist[found])).all() and (dist[found] < 2 ** 31).all():   # Hamming: integers
+            out = np.full(dist.shape, np.iinfo(np.int32).max, np.int32)
+            out[found] = dist[found].astype(np.int32)
+        else:                                     # a float norm (cv2.BFMatcher() on SIFT): float32, as cv2 holds it
+            out = np.full(dist.shape, np.finfo(np.float32).max, np.float32)
+            out[found] = dist[found].astype(np.float32)
+        return idx, out, None
 
     def find_matching_features(self, with_significance_test=False, debug=False, row_thresh=None):
         """Match the current frame's left descriptors against its right descriptors
@@ -327,7 +401,10 @@ class Matcher:
     @staticmethod
     def apply_thresholds(matches, threshold):
         """keep [m] iff m.distance < threshold * n.distance (models/Matcher.py:178-184).
-        Raises if a query has fewer than two neighbours, as unpacking `for m, n in` does."""
+        Raises if a query has fewer than two neighbours, as unpacking `for m, n in` does.
+        Integer (Hamming) distances are tested on the GPU (slam_ratio_filter: the same fp64
+        compare); float distances (an L2 matcher's), or match lists handled on a machine
+        without a GPU, are compared here exactly as the reference's loop does."""
         n = len(matches)
         if n == 0:
             return []
@@ -336,11 +413,14 @@ class Matcher:
         exact = True
         for i, pair in enumerate(matches):
             m, nn = pair  # ValueError on a short list, like the reference
-            idx[i] = (m.trainIdx, nn.trainIdx)
-            dist[i] = (int(m.distance), int(nn.distance))
-            exact = exact and dist[i, 0] == m.distance and dist[i, 1] == nn.distance
-        if not exact:
-            raise ValueError("apply_thresholds: the GPU ratio test takes integer (Hamming) distances")
+            d0, d1 = m.distance, nn.distance
+            if exact and d0 == int(d0) and d1 == int(d1) and 0 <= d0 < 2 ** 31 and 0 <= d1 < 2 ** 31:
+                idx[i] = (m.trainIdx, nn.trainIdx)
+                dist[i] = (int(d0), int(d1))
+            else:
+                exact = False
+        if not exact or not torch.cuda.is_available():
+            return [[m] for m, nn in matches if m.distance < threshold * nn.distance]
         dev = _default_device()
         keep = ops.ratio_filter(torch.from_numpy(idx).to(dev), torch.from_numpy(dist).to(dev), threshold).cpu().numpy()
         return [[matches[i][0]] for i in np.flatnonzero(keep)]
@@ -382,6 +462,8 @@ class Matcher:
                 entry[FILTERED_MATCHES] = [m if isinstance(m, dict) else self.dmatch_to_dict(m)
                                            for m in entry[FILTERED_MATCHES]]
             entry[CONSECUTIVE] = None
+        self._stereo_keep = {}
+        self._synced_frame = None
 
     def keypoint_to_dict(self, keypoint):
         return {'pt': keypoint.pt, 'size': keypoint.size, 'angle': keypoint.angle, 'response': keypoint.response,
@@ -389,6 +471,12 @@ class Matcher:
 
     def dmatch_to_dict(self, dmatch):
         return {'queryIdx': dmatch[0].queryIdx, 'trainIdx': dmatch[0].trainIdx, 'distance': dmatch[0].distance}
+
+
+def _keypoint_from_dict(d):
+    x, y = d['pt']
+    return KeyPoint(x, y, d.get('size', 1.0), d.get('angle', -1.0), d.get('response', 0.0), d.get('octave', 0),
+                    d.get('class_id', -1))
 
 
 def _as_object_array(kps):

@@ -197,10 +197,12 @@ def chain_poses(rel_poses, first=None):
     return ex, cam
 
 
-def replay_tracks(shards, first_frame=0):
+def replay_tracks(shards, first_frame=0, first=None):
     """Sequential tail on rank 0: rebuild the track database from gathered shard tables
     (in rank order = frame order) exactly as the frame loop would have fed it
-    (utils/utils.py:277-292)."""
+    (utils/utils.py:277-292).  first: extrinsic matrix of the first frame of the shards (the
+    reference starts the chain at M1, utils/utils.py:244-245; default [I|0]); ex_matrices and
+    camera_positions are indexed from that frame (row 0 = first_frame)."""
     db = TrackDatabase()
     poses = []
     frame = first_frame
@@ -214,7 +216,7 @@ def replay_tracks(shards, first_frame=0):
         if gc_was_on:
             gc.enable()
     if poses:
-        ex, cam = chain_poses(np.stack(poses))
+        ex, cam = chain_poses(np.stack(poses), first=first)
         db.set_ex_matrices(ex)
         db.set_ex_camera_positions(cam)
     return db

@@ -77,7 +77,7 @@ def track_camera_device(frames, seed=6, n_hyp=VO_MAX_ITERATIONS, cameras=None, t
     torch.cuda.synchronize()
     found = ws.found.cpu().numpy()[:ws.P]
     assert found.all(), f"RANSAC Couldn't find a transformation from frame {int(np.argmin(found))} to the next one"
-    db = replay_tracks(TableGather(ws, pose="pose").run())
+    db = replay_tracks(TableGather(ws, pose="pose").run(), first=m1)
     return np.asarray(db.camera_positions), db
 
 
