@@ -274,6 +274,35 @@ int slam_score_hypotheses(const double *Rt_dev, int n_sets, int H,
                           void *stream);
 
 /*
+ * slam_score_hypotheses for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference: this is slam_score_hypotheses(..., masks = NULL, work = <built in>), where the
+ * workspace is a fixed array inside the library's code object (one copy per GPU, held until the
+ * process ends) instead of a caller-owned buffer.  The call itself makes no hipMalloc / hipFree
+ * and no allocating library call.  Counts are identical to slam_score_hypotheses.
+ *
+ * Limit: n_sets * max(cap, 1) <= SLAM_SCORE_STATIC_MAX_POINTS point slots (the workspace is
+ * SLAM_SCORE_WORK_PER_POINT doubles per slot = 12 MiB); larger batches are refused with
+ * SLAM_ERR_UNSUPPORTED and must bring their own workspace.
+ * All calls made with the same GPU current share that GPU's array, whatever their stream: two
+ * such calls that overlap in time race on it.  Calls on one stream, or otherwise ordered, are
+ * safe -- every call rebuilds the whole workspace contents it reads.
+ * The first call on a device resolves the array's address (hipGetSymbolAddress); make that
+ * first call outside any graph capture.
+ */
+#define SLAM_SCORE_WORK_PER_POINT 24
+#define SLAM_SCORE_STATIC_MAX_POINTS 65536
+#define SLAM_SCORE_STATIC_WORK_DOUBLES (SLAM_SCORE_WORK_PER_POINT * SLAM_SCORE_STATIC_MAX_POINTS)
+int slam_score_hypotheses_static(const double *Rt_dev, int n_sets, int H,
+                                 const double *K_host, const double *t_right_host,
+                                 const double *X_dev, const double *Y_dev,
+                                 const double *Z_dev, const float *uL_dev,
+                                 const float *vL_dev, const float *uR_dev,
+                                 const float *vR_dev, int cap, const int32_t *n_dev,
+                                 int n_host, double thresh, int32_t *counts_dev,
+                                 void *stream);
+
+/*
  * The same for hypotheses [h_begin, h_begin + H) of each set only (Rt, counts and masks keep
  * their row stride of H_total hypotheses per set), leaving alone every set whose entry in
  * skip_dev [n_sets] (nullable) is non-zero.  This is how the batched RANSAC scores a first

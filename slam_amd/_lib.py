@@ -27,6 +27,7 @@ EXPORTS = (
     "slam_join_consensus_prepared",
     "slam_score_hypotheses",
     "slam_score_hypotheses_range",
+    "slam_score_hypotheses_static",
     "slam_select_best",
     "slam_build_inlier_tables",
     "slam_winner_tables",
@@ -93,6 +94,8 @@ def load():
     lib.slam_score_hypotheses_range.restype = ci
     lib.slam_score_hypotheses_range.argtypes = ([vp, ci, ci, ci, ci, vp, vp, vp] + [vp] * 7 +
                                                 [ci, vp, ci, cd, vp, vp, ci, vp, ci, vp])
+    lib.slam_score_hypotheses_static.restype = ci
+    lib.slam_score_hypotheses_static.argtypes = [vp, ci, ci, vp, vp] + [vp] * 7 + [ci, vp, ci, cd, vp, vp]
     lib.slam_select_best.restype = ci
     lib.slam_select_best.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
     lib.slam_build_inlier_tables.restype = ci

@@ -30,6 +30,7 @@
 //                     ~60 plus four divisions and two square roots).
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -1063,4 +1064,65 @@ extern "C" int slam_score_hypotheses_range(const double *Rt, int n_sets, int H_t
     }
     hipLaunchKernelGGL(score_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
     return check_launch("slam_score_hypotheses");
+}
+
+// ---- the entry point that allocates nothing -------------------------------------------------
+// Same scoring as slam_score_hypotheses with a workspace, but the workspace is this array: a
+// fixed piece of every GPU's memory that comes with the code object, so the call needs no
+// hipMalloc from anyone (callers under graph capture, serving loops, harnesses that forbid
+// allocation).  Each GPU has its own copy at its own address; the name below is only a host-side
+// handle, the address a kernel can use comes from hipGetSymbolAddress with that GPU current.
+static_assert(SLAM_SCORE_WORK_PER_POINT >= slam::SCORE_WORK_PER_REC + slam::SCORE_HDR, "workspace per point slot");
+static __device__ __align__(256) double scratch[(size_t)SLAM_SCORE_STATIC_WORK_DOUBLES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex scratch_lock;
+double *scratch_ptr[MAX_DEVICES];     // per device, filled on the first call made with that device current
+
+int scratch_for_current_device(double **out)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess)
+        return fail(SLAM_ERR_LAUNCH, "slam_score_hypotheses_static: hipGetDevice: %s", hipGetErrorString(e));
+    if (dev < 0 || dev >= MAX_DEVICES)
+        return fail(SLAM_ERR_UNSUPPORTED, "slam_score_hypotheses_static: device %d out of range", dev);
+    std::lock_guard<std::mutex> guard(scratch_lock);
+    if (!scratch_ptr[dev]) {
+        double *p = nullptr;
+        e = hipGetSymbolAddress(reinterpret_cast<void **>(&p), HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return fail(SLAM_ERR_LAUNCH, "slam_score_hypotheses_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+        scratch_ptr[dev] = p;
+    }
+    *out = scratch_ptr[dev];
+    return SLAM_OK;
+}
+}  // namespace
+
+extern "C" int slam_score_hypotheses_static(const double *Rt, int n_sets, int H, const double *K,
+                                            const double *t_right, const double *X, const double *Y, const double *Z,
+                                            const float *uL, const float *vL, const float *uR, const float *vR, int cap,
+                                            const int32_t *n_dev, int n_host, double thresh, int32_t *counts,
+                                            void *stream)
+{
+    if (n_sets < 0 || H < 0 || cap < 0)
+        return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses_static: negative size");
+    const long long need = (long long)SLAM_SCORE_WORK_PER_POINT * n_sets * (cap > 1 ? cap : 1);
+    if (need > (long long)SLAM_SCORE_STATIC_WORK_DOUBLES)
+        return fail(SLAM_ERR_UNSUPPORTED,
+                    "slam_score_hypotheses_static: n_sets * cap = %lld point slots exceed the built-in workspace of %d "
+                    "(use slam_score_hypotheses with a caller-owned workspace)",
+                    (long long)n_sets * (cap > 1 ? cap : 1), SLAM_SCORE_STATIC_MAX_POINTS);
+    if (n_sets == 0 || H == 0)
+        return SLAM_OK;
+    double *work = nullptr;
+    const int st = scratch_for_current_device(&work);
+    if (st != SLAM_OK)
+        return st;
+    // work_ready = 0: the point records and per-set bounds are rebuilt (and the bounds cleared) by
+    // every call, so nothing of the previous call's contents is relied on
+    return slam_score_hypotheses_range(Rt, n_sets, H, 0, H, nullptr, K, t_right, X, Y, Z, uL, vL, uR, vR, cap, n_dev,
+                                       n_host, thresh, counts, nullptr, 0, work, 0, stream);
 }
