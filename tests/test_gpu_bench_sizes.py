@@ -1,0 +1,238 @@
+"""GPU parity at the benchmark's own sizes and kernel selections.
+
+* the headline workload exactly -- 2000 keypoints, 61-byte descriptors, 10 000 seeded hypotheses
+  per pair, enough pairs that the library picks the same scoring kernel form as in bench.py,
+  no variant forced -- every count, winner and inlier table against the C oracle;
+* a KITTI-00-length sequence (4541 frames x 2000 keypoints) in ONE batch through the device
+  RANSAC: size-independent properties on every row of every frame, exact oracle parity on frames
+  and pairs spread over the range (catches 32-bit offset and grid-size trouble at 9 M rows);
+* a reduced loop-closure sweep: every keyframe against all earlier ones through
+  vo.loop_closure_batched, each pair against the oracle's per-pair pipeline.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu as oracle
+from oracle import numpy_twin as twin
+from slam_amd import pipeline, sharding, vo
+from slam_amd.synthetic import SyntheticSequence, read_cameras, seeded_hypotheses
+
+pytestmark = pytest.mark.gpu
+
+_POP8 = np.array([bin(i).count("1") for i in range(256)], dtype=np.int32)
+
+
+def _ham(a, b):
+    return _POP8[np.bitwise_xor(a, b)].sum(axis=1)
+
+
+def _oracle_stereo(fr, P, Q, threads=8):
+    idx, dist = oracle.hamming_knn(fr.descL, fr.descR, 1, threads=threads)
+    keep = oracle.row_filter(idx, fr.kpL[:, 1], fr.kpR[:, 1], 2.0)
+    j = np.where(keep > 0, idx[:, 0], 0)
+    X, Y, Z, valid = oracle.triangulate_dlt(P, Q, fr.kpL[:, 0], fr.kpL[:, 1], fr.kpR[j, 0], fr.kpR[j, 1], threads=threads)
+    return dict(idx=idx, dist=dist, keep=keep, smap=np.where(keep > 0, idx[:, 0], -1).astype(np.int32),
+                valid=(valid * (keep > 0)).astype(np.uint8), X=X, Y=Y, Z=Z)
+
+
+def _oracle_pair(fa, fb, sa, sb, ratio, threads=8):
+    """Consensus rows and point arrays of one (reference, candidate) pair from the oracle."""
+    tidx, tdist = oracle.hamming_knn(fa.descL, fb.descL, 2, threads=threads)
+    tkeep = oracle.ratio_filter(tidx, tdist, ratio)
+    rows = oracle.join(tidx, tkeep, sa["smap"], sa["valid"], sb["smap"])
+    pts = (sa["X"][rows[:, 0]], sa["Y"][rows[:, 0]], sa["Z"][rows[:, 0]], fb.kpL[rows[:, 2], 0], fb.kpL[rows[:, 2], 1],
+           fb.kpR[rows[:, 3], 0], fb.kpR[rows[:, 3], 1])
+    return tidx, tdist, tkeep, rows, pts
+
+
+def _mask_bits(mask_words, n):
+    return np.unpackbits(mask_words.view(np.uint8), bitorder="little")[:n].astype(bool)
+
+
+def test_headline_workload_counts_winners_and_tables(device, monkeypatch):
+    """BASELINE configs[1] as bench.py runs it: 2000 keypoints, H = 10 000, default kernels."""
+    for var in ("SLAM_SCORE_IMPL", "SLAM_KNN_IMPL"):
+        monkeypatch.delenv(var, raising=False)
+    k, m1, m2 = read_cameras()
+    Pm, Qm = k @ m1, k @ m2
+    n_pairs, H = 24, 10000          # 24 x ceil(10000/64) blocks: past the point where the wide kernel form is chosen
+    seq = SyntheticSequence(2000, n_pairs + 1)
+    Rt_host = np.stack([seeded_hypotheses(seq.relative_pose(p, p + 1), H, seed=6 + p) for p in range(n_pairs)])
+    fe = pipeline.FrontEnd(k, m1, m2)
+    tb = pipeline.FrameTables.from_frames(seq.frames, device)
+    ws = fe.prepare(tb, n_hyp=H)
+    fe.run(ws, torch.from_numpy(Rt_host).to(device))
+    torch.cuda.synchronize()
+    counts = ws.counts.cpu().numpy()
+    best, best_count, n_inl = ws.best.cpu().numpy(), ws.best_count.cpu().numpy(), ws.n_inl.cpu().numpy()
+    inl_rows, inl_loc = ws.inl_rows.cpu().numpy(), ws.inl_loc.cpu().numpy()
+    cons = pipeline.consensus_to_host(ws)
+    st = [_oracle_stereo(f, Pm, Qm) for f in seq.frames]
+    off = 0
+    for p in range(n_pairs):
+        fa, fb = seq.frames[p], seq.frames[p + 1]
+        _, _, _, rows, pts = _oracle_pair(fa, fb, st[p], st[p + 1], 1.0)
+        assert np.array_equal(cons[p]["rows"], rows)
+        rc = oracle.score_hypotheses(Rt_host[p], k, m2[:, 3], *pts, 2.0, threads=8)
+        assert np.array_equal(counts[p], rc), p                     # all 10 000 counts
+        w = int(np.argmax(rc))                                      # first best, as the strict '>' update keeps it
+        assert (int(best[p]), int(best_count[p]), int(n_inl[p])) == (w, int(rc[w]), int(rc[w]))
+        _, m = oracle.score_hypotheses(Rt_host[p, w][None], k, m2[:, 3], *pts, 2.0, want_masks=True)
+        bits = _mask_bits(m[0], len(rows))
+        sel = rows[bits]
+        assert np.array_equal(inl_rows[off:off + len(sel)], sel)
+        loc = np.stack([fa.kpL[sel[:, 0], 0], fa.kpR[sel[:, 1], 0], fa.kpL[sel[:, 0], 1],
+                        fb.kpL[sel[:, 2], 0], fb.kpR[sel[:, 3], 0], fb.kpL[sel[:, 2], 1]], axis=1)
+        assert np.array_equal(inl_loc[off:off + len(sel)], loc)
+        off += len(sel)
+
+
+@pytest.mark.timeout(600)
+def test_full_sequence_length_in_one_batch(device):
+    """BASELINE configs[2]: 4541 frames x 2000 keypoints through FrontEnd.run_ransac."""
+    n_frames = int(os.environ.get("SLAM_TEST_FULL_FRAMES", "4541"))
+    n_kp, H = 2000, 256
+    k, m1, m2 = read_cameras()
+    Pm, Qm = k @ m1, k @ m2
+    seq = SyntheticSequence(n_kp, n_frames)
+    P = n_frames - 1
+    fe = pipeline.FrontEnd(k, m1, m2)
+    tb = pipeline.FrameTables.from_frames(seq.frames, device)
+    assert int(tb.offL[-1]) == n_frames * n_kp
+    ws = fe.prepare(tb, n_hyp=H)
+    fe.run_ransac(ws, seed=6)
+    torch.cuda.synchronize()
+    s_idx, s_dist, s_keep = ws.s_idx.cpu().numpy(), ws.s_dist.cpu().numpy(), ws.s_keep.cpu().numpy()
+    t_idx, t_dist, t_keep = ws.t_idx.cpu().numpy(), ws.t_dist.cpu().numpy(), ws.t_keep.cpu().numpy()
+    smap, valid = ws.smap.cpu().numpy(), ws.valid.cpu().numpy()
+    Z = ws.Z.cpu().numpy()
+    n_cons = ws.cons.count.cpu().numpy()[:P]
+    n_inl = ws.n_inl.cpu().numpy()[:P]
+    found = ws.found.cpu().numpy()[:P]
+    iters = ws.iters.cpu().numpy()[:P]
+    pose = ws.pose.cpu().numpy()[:P].reshape(P, 3, 4)
+
+    # ---- properties that hold for every row of every frame ---------------------------------------
+    assert s_idx[:, 0].min() >= 0 and s_idx[:, 0].max() < n_kp and (s_idx[:, 1] == -1).all()
+    assert t_idx[: P * n_kp].min() >= 0 and t_idx[: P * n_kp].max() < n_kp
+    for f, fr in enumerate(seq.frames):
+        s = slice(f * n_kp, (f + 1) * n_kp)
+        idx = s_idx[s, 0]
+        assert np.array_equal(_ham(fr.descL, fr.descR[idx]), s_dist[s, 0]), f
+        dev = np.abs(fr.kpL[:, 1].astype(np.float64) - fr.kpR[idx, 1].astype(np.float64))
+        assert np.array_equal(s_keep[s].astype(bool), dev <= 2.0), f
+        assert np.array_equal(smap[s], np.where(s_keep[s] > 0, idx, -1)), f
+        ok = valid[s] > 0
+        assert not (ok & (s_keep[s] == 0)).any() and (Z[s][ok] > 0).all(), f
+        true = fr.idL >= 0
+        assert (fr.idR[idx[true]] == fr.idL[true]).mean() > 0.995, f
+        if f < P:
+            nx = seq.frames[f + 1]
+            i2, d2 = t_idx[s], t_dist[s]
+            assert np.array_equal(_ham(fr.descL, nx.descL[i2[:, 0]]), d2[:, 0]), f
+            assert np.array_equal(_ham(fr.descL, nx.descL[i2[:, 1]]), d2[:, 1]), f
+            assert ((d2[:, 0] < d2[:, 1]) | ((d2[:, 0] == d2[:, 1]) & (i2[:, 0] < i2[:, 1]))).all(), f
+            assert np.array_equal(t_keep[s].astype(bool), d2[:, 0].astype(np.float64) < 1.0 * d2[:, 1]), f
+    assert found.all() and (n_cons > 0.3 * 0.6 * n_kp).all() and (n_inl > 0.9 * n_cons).all()
+    assert (iters < H).all()                                        # the stopping rule fired everywhere
+    gt = np.stack([seq.relative_pose(p, p + 1) for p in range(P)])
+    assert np.abs(pose - gt).max() < 0.05
+
+    # ---- exact oracle parity on frames / pairs spread over the range -------------------------------
+    cons_rows = ws.cons.rows.cpu().numpy()
+    cap = ws.cap
+    inl_off = np.concatenate([[0], np.cumsum(n_inl)])
+    inl_rows = ws.inl_rows.cpu().numpy()
+    inl_loc = ws.inl_loc.cpu().numpy()
+    samples, counts = ws.samples.cpu().numpy(), ws.counts.cpu().numpy()
+    ref_Rt, best = ws.ref_Rt.cpu().numpy(), ws.best.cpu().numpy()
+    Rt_gen = ws.Rt_gen
+    picks = sorted({0, 1, P // 4, P // 2, (3 * P) // 4, P - 2, P - 1})
+    picks = [p for p in picks if 0 <= p < P]
+    assert np.array_equal(samples[picks], oracle.ransac_sample(6, P, H, n_cons)[picks])
+    for p in picks:
+        fa, fb = seq.frames[p], seq.frames[p + 1]
+        sa, sb = _oracle_stereo(fa, Pm, Qm), _oracle_stereo(fb, Pm, Qm)
+        s = slice(p * n_kp, (p + 1) * n_kp)
+        assert np.array_equal(s_idx[s, 0], sa["idx"][:, 0]) and np.array_equal(s_dist[s, 0], sa["dist"][:, 0])
+        assert np.array_equal(smap[s], sa["smap"]) and np.array_equal(valid[s], sa["valid"])
+        tidx, tdist, tkeep, rows, pts = _oracle_pair(fa, fb, sa, sb, 1.0)
+        assert np.array_equal(t_idx[s], tidx) and np.array_equal(t_dist[s], tdist) and np.array_equal(t_keep[s], tkeep)
+        assert int(n_cons[p]) == len(rows) and np.array_equal(cons_rows[p * cap:p * cap + len(rows)], rows)
+        # the hypotheses the rule looked at, scored by the oracle: same counts, same stop, same winner
+        first = 128                                             # the slice scored before the rule is consulted
+        poses = Rt_gen[p, :first].cpu().numpy()
+        with np.errstate(all="ignore"):
+            rc = oracle.score_hypotheses(poses, k, m2[:, 3], *pts, 2.0, threads=8)
+        assert np.array_equal(counts[p, :first], rc)
+        want_best, want_iters = twin.ransac_stop_replay(rc, len(rows), first)
+        assert want_iters < first and (int(best[p]), int(iters[p])) == (want_best, want_iters)
+        # the inlier table is the refined pose's supporters, in consensus order, with their locations
+        c, m = oracle.score_hypotheses(ref_Rt[p][None], k, m2[:, 3], *pts, 2.0, want_masks=True)
+        sel = rows[_mask_bits(m[0], len(rows))]
+        assert int(n_inl[p]) == int(c[0]) == len(sel)
+        assert np.array_equal(inl_rows[inl_off[p]:inl_off[p + 1]], sel)
+        loc = np.stack([fa.kpL[sel[:, 0], 0], fa.kpR[sel[:, 1], 0], fa.kpL[sel[:, 0], 1],
+                        fb.kpL[sel[:, 2], 0], fb.kpR[sel[:, 3], 0], fb.kpL[sel[:, 2], 1]], axis=1)
+        assert np.array_equal(inl_loc[inl_off[p]:inl_off[p + 1]], loc)
+
+    # ---- the track store built from the tables: every inlier row is one link of one track ---------
+    db = sharding.replay_tracks(sharding.TableGather(ws, pose="pose").run(), first=m1)
+    assert db.get_num_frames() == n_frames
+    lengths = db.get_track_length_data()
+    assert int((lengths - 1).sum()) == int(n_inl.sum())
+    # dead reckoning over 3.6 km: the chained positions drift with the accumulated yaw error, a few per cent of the path
+    path = 0.8 * P
+    assert np.abs(np.asarray(db.camera_positions) - sharding.chain_poses(gt, first=m1)[1]).max() < 0.1 * path
+
+
+def test_loop_closure_sweep_against_the_oracle(device):
+    """BASELINE configs[4]'s loop-closure part, reduced: all keyframes against all earlier ones."""
+    k, m1, m2 = read_cameras()
+    Pm, Qm = k @ m1, k @ m2
+    n_kf, n_kp, H = 14, 1500, 500
+    seq = SyntheticSequence(n_kp, n_kf, seed=31, step=1.5)
+    pairs = np.asarray([(i, j) for i in range(n_kf) for j in range(n_kf) if i - j >= 2], dtype=np.int64)
+    res = vo.loop_closure_batched(seq.frames, pairs, thresh=0.6, n_hyp=H, seed=6)
+    ws = res["workspace"]
+    P = len(pairs)
+    assert ws.P == P == 78
+    cap = ws.cap
+    cons_rows = ws.cons.rows.cpu().numpy()
+    counts = ws.counts.cpu().numpy()
+    t_idx, t_keep = ws.t_idx.cpu().numpy(), ws.t_keep.cpu().numpy()
+    ref_Rt = ws.ref_Rt.cpu().numpy()
+    n_inl = ws.n_inl.cpu().numpy()[:P]
+    inl_off = np.concatenate([[0], np.cumsum(n_inl)])
+    inl_rows = ws.inl_rows.cpu().numpy()
+    st = [_oracle_stereo(f, Pm, Qm) for f in seq.frames]
+    n_valid = 0
+    for p, (a, b) in enumerate(pairs):
+        fa, fb = seq.frames[a], seq.frames[b]
+        tidx, tdist, tkeep, rows, pts = _oracle_pair(fa, fb, st[a], st[b], 0.6)
+        s = slice(int(ws.t_off[p]), int(ws.t_off[p]) + n_kp)
+        assert np.array_equal(t_idx[s], tidx) and np.array_equal(t_keep[s], tkeep), (a, b)
+        assert int(res["n_filtered_matches"][p]) == int(tkeep.sum())
+        assert int(res["n_consensus"][p]) == len(rows) and np.array_equal(cons_rows[p * cap:p * cap + len(rows)], rows)
+        if len(rows) < 4:
+            assert not res["valid"][p]
+            continue
+        first = min(128, H)
+        with np.errstate(all="ignore"):
+            rc = oracle.score_hypotheses(ws.Rt_gen[p, :first].cpu().numpy(), k, m2[:, 3], *pts, 2.0, threads=8)
+        assert np.array_equal(counts[p, :first], rc), (a, b)
+        c, m = oracle.score_hypotheses(ref_Rt[p][None], k, m2[:, 3], *pts, 2.0, want_masks=True)
+        sel = rows[_mask_bits(m[0], len(rows))]
+        assert int(n_inl[p]) == len(sel) and np.array_equal(inl_rows[inl_off[p]:inl_off[p + 1]], sel), (a, b)
+        assert not res["valid"][p] or len(rows) >= 10             # the reference gives up below 10 consensus matches
+        assert res["valid"][p] or len(rows) < 10 or rc.max() == 0
+        if res["valid"][p]:
+            n_valid += 1
+            assert res["inliers_ratio"][p] == len(sel) / len(rows)
+            gt = seq.relative_pose(a, b)
+            if len(sel) >= 30:
+                assert np.abs(res["pose"][p][:, :3] - gt[:, :3]).max() < 2e-2, (a, b)
+    assert n_valid >= 20          # near keyframes overlap; far ones have nothing in common and are reported invalid
