@@ -113,3 +113,30 @@ def test_pipeline_select_gather_replay_equals_oracle_tables(device):
     db = sharding.replay_tracks(shards)
     assert db == sharding.replay_tracks([ref])
     assert db.get_max_track() == n_frames
+
+
+def test_winner_tables_and_replay_equal_the_reference_track_store(device):
+    """GPU winner tables -> gather -> sequential replay against the state the REFERENCE's own
+    models/TrackDatabase.py reached on the same mini-sequence (tests/golden/trackdb_golden.npz,
+    generated by importing the reference class: tests/golden/make_trackdb_golden.py)."""
+    from trackdb_state import assert_same, query_arrays, state_arrays
+    T = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trackdb_golden.npz"))
+    k, m1, m2 = read_cameras()
+    n_kp, n_frames, H = int(T["mini_n_kp"]), int(T["mini_n_frames"]), int(T["mini_H"])
+    seq = SyntheticSequence(n_kp, n_frames)
+    P = n_frames - 1
+    Rt_host = np.stack([seeded_hypotheses(seq.relative_pose(p, p + 1), H, seed=6 + p) for p in range(P)])
+    fe = pipeline.FrontEnd(k, m1, m2)
+    tb = pipeline.FrameTables.from_frames(seq.frames, device)
+    ws = fe.prepare(tb, n_hyp=H)
+    fe.run(ws, torch.from_numpy(Rt_host).to(device))
+    torch.cuda.synchronize()
+    assert np.array_equal(ws.best.cpu().numpy()[:P], T["mini_best"])
+    assert np.array_equal(ws.n_inl.cpu().numpy()[:P], T["mini_n_inl"])
+    assert np.array_equal(ws.cons.count.cpu().numpy()[:P], T["mini_n_cons"])
+    n = int(T["mini_n_inl"].sum())
+    assert np.array_equal(ws.inl_rows.cpu().numpy()[:n], T["mini_rows"])
+    assert np.array_equal(ws.inl_loc.cpu().numpy()[:n], T["mini_loc"])
+    db = sharding.replay_tracks(sharding.TableGather(ws, 1, 0).run(), first=m1)
+    want = {key[len("mini_state_"):]: T[key] for key in T.files if key.startswith("mini_state_")}
+    assert_same({**state_arrays(db), **query_arrays(db)}, want, "gpu tables -> replay")
