@@ -15,6 +15,7 @@
 #ifndef SLAM_AMD_H
 #define SLAM_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -378,6 +379,38 @@ int slam_winner_tables(const int32_t *pair_dev, int n_pairs, const int32_t *rows
                        const float *xL_dev, const float *yL_dev, const float *xR_dev,
                        int32_t *inl_rows_dev, float *inl_loc_dev, int32_t *n_inl_dev,
                        void *stream);
+
+/*
+ * Track ids and the track-point table of a whole run of consecutive frame pairs, on the device.
+ * Replaces: the row-by-row bookkeeping of TrackDatabase.update_tracks_from_frame / add_to_track /
+ * get_kp_trackId / generate_new_track_id / prepare_to_next_pair (models/TrackDatabase.py:34-76,
+ * 166-184) over the inlier tables of slam_winner_tables / slam_build_inlier_tables.
+ *
+ * inl_rows [cap_rows,4] int32 / inl_loc [cap_rows,6] f32: the dense inlier tables (pair p's rows
+ * follow pair p-1's), n_inl [n_pairs]; pair p is frames (first_frame + p, first_frame + p + 1).
+ * kp_cap: every keypoint index in columns 0 and 2 is < kp_cap.
+ * A row of pair p continues the track of the LAST row of pair p-1 whose cur_left equals its
+ * prev_left, else it opens track number (tracks opened before it in (pair, row) order).
+ * Outputs:
+ *   row_track, row_depth [cap_rows]   track id of every row, and its position in the track minus 1
+ *   track_start [cap_rows + 1]        first point slot of track t; track_start[n_tracks] = n_points
+ *   pt_kp, pt_frame [2 cap_rows], pt_loc [2 cap_rows, 3]
+ *                                     per track point, tracks back to back in id order, points in
+ *                                     frame order: left keypoint index, frame id, (xl, xr, yl) --
+ *                                     the tuples of models/TrackDatabase.py:57-58
+ *   summary [8] int32: [0] rows, [1] tracks, [2] points, [3] longest track in points,
+ *                      [4] flags: 1 = two rows of one pair continue the same row (then the point
+ *                      table is not what the reference builds: replay on the host instead),
+ *                      2 = a keypoint index >= kp_cap, 4 = sum(n_inl) > cap_rows (nothing done)
+ * work: slam_track_assign_work_bytes(n_pairs, cap_rows, kp_cap) bytes, 256-byte aligned.
+ */
+size_t slam_track_assign_work_bytes(int n_pairs, int cap_rows, int kp_cap);
+int slam_track_assign(const int32_t *inl_rows_dev, const float *inl_loc_dev,
+                      const int32_t *n_inl_dev, int n_pairs, int cap_rows, int kp_cap,
+                      int first_frame, int32_t *row_track_dev, int32_t *row_depth_dev,
+                      int32_t *track_start_dev, int32_t *pt_kp_dev, int32_t *pt_frame_dev,
+                      float *pt_loc_dev, int32_t *summary_dev, void *work_dev,
+                      size_t work_bytes, void *stream);
 
 /* ---- batched PnP-RANSAC around slam_score_hypotheses --------------------------------
  * ransac_for_pnp (utils/utils.py:413-464) for many point sets at once.  The reference

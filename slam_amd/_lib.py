@@ -31,6 +31,8 @@ EXPORTS = (
     "slam_select_best",
     "slam_build_inlier_tables",
     "slam_winner_tables",
+    "slam_track_assign_work_bytes",
+    "slam_track_assign",
     "slam_ransac_sample",
     "slam_p3p_hypotheses",
     "slam_ransac_select",
@@ -102,6 +104,10 @@ def load():
     lib.slam_build_inlier_tables.argtypes = [vp, ci, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.slam_winner_tables.restype = ci
     lib.slam_winner_tables.argtypes = [vp, ci, vp, vp, ci, vp, vp, cd] + [vp] * 16
+    lib.slam_track_assign_work_bytes.restype = ctypes.c_size_t
+    lib.slam_track_assign_work_bytes.argtypes = [ci, ci, ci]
+    lib.slam_track_assign.restype = ci
+    lib.slam_track_assign.argtypes = [vp, vp, vp, ci, ci, ci, ci] + [vp] * 8 + [ctypes.c_size_t, vp]
     lib.slam_ransac_sample.restype = ci
     lib.slam_ransac_sample.argtypes = [ctypes.c_uint64, ci, ci, vp, ci, vp, vp]
     lib.slam_p3p_hypotheses.restype = ci

@@ -236,7 +236,133 @@ done:
     return result;
 }
 
+/* build_tracks(pt_kp int32 [N], pt_frame int32 [N], pt_loc float32 [N,3], track_start int32 [n+1], n)
+ *   -> {track id: [(kp, (xl, xr, yl), frame), ...]} for tracks 0 .. n-1
+ * The dict-of-lists form of a track-point table that is laid out track after track (CSR). */
+static PyObject *build_tracks(PyObject *Py_UNUSED(self), PyObject *args)
+{
+    Py_buffer kp_b, fr_b, loc_b, st_b;
+    long n_tracks;
+    if (!PyArg_ParseTuple(args, "y*y*y*y*l", &kp_b, &fr_b, &loc_b, &st_b, &n_tracks))
+        return NULL;
+    PyObject *tracks = NULL, *result = NULL;
+    PyObject **small = NULL;           /* shared int objects for keypoint indices and frame ids */
+    long n_small = 0;
+    const int32_t *kp = (const int32_t *)kp_b.buf, *fr = (const int32_t *)fr_b.buf, *st = (const int32_t *)st_b.buf;
+    const float *loc = (const float *)loc_b.buf;
+    const Py_ssize_t N = kp_b.len / (Py_ssize_t)sizeof(int32_t);
+    if (n_tracks < 0 || st_b.len / (Py_ssize_t)sizeof(int32_t) < n_tracks + 1 ||
+        fr_b.len / (Py_ssize_t)sizeof(int32_t) < N || loc_b.len / (Py_ssize_t)(3 * sizeof(float)) < N) {
+        PyErr_SetString(PyExc_ValueError, "build_tracks: tables shorter than the track table says");
+        goto done;
+    }
+    if (n_tracks > 0 && (st[0] != 0 || st[n_tracks] > N)) {
+        PyErr_SetString(PyExc_ValueError, "build_tracks: track_start does not fit the point table");
+        goto done;
+    }
+    for (Py_ssize_t i = 0; i < (n_tracks ? st[n_tracks] : 0); ++i) {
+        if (kp[i] < 0 || fr[i] < 0) {
+            PyErr_SetString(PyExc_ValueError, "build_tracks: negative keypoint index or frame id");
+            goto done;
+        }
+        if (kp[i] >= n_small)
+            n_small = (long)kp[i] + 1;
+        if (fr[i] >= n_small)
+            n_small = (long)fr[i] + 1;
+    }
+    small = (PyObject **)calloc(n_small ? (size_t)n_small : 1, sizeof(PyObject *));
+    tracks = PyDict_New();
+    if (!small || !tracks) {
+        PyErr_NoMemory();
+        goto done;
+    }
+    for (long t = 0; t < n_tracks; ++t) {
+        const Py_ssize_t a = st[t], b = st[t + 1];
+        if (b < a) {
+            PyErr_SetString(PyExc_ValueError, "build_tracks: track_start must not decrease");
+            goto done;
+        }
+        PyObject *lst = PyList_New(b - a);
+        PyObject *tid = PyLong_FromLong(t);
+        int ok = lst && tid;
+        for (Py_ssize_t i = a; ok && i < b; ++i) {
+            if (!small[kp[i]])
+                small[kp[i]] = PyLong_FromLong(kp[i]);
+            if (!small[fr[i]])
+                small[fr[i]] = PyLong_FromLong(fr[i]);
+            PyObject *pt = (small[kp[i]] && small[fr[i]]) ? track_point(small[kp[i]], loc + 3 * i, small[fr[i]]) : NULL;
+            if (!pt)
+                ok = 0;
+            else
+                PyList_SET_ITEM(lst, i - a, pt);
+        }
+        ok = ok && PyDict_SetItem(tracks, tid, lst) == 0;
+        Py_XDECREF(lst);
+        Py_XDECREF(tid);
+        if (!ok)
+            goto done;
+    }
+    result = tracks;
+    tracks = NULL;
+done:
+    Py_XDECREF(tracks);
+    if (small)
+        for (long i = 0; i < n_small; ++i)
+            Py_XDECREF(small[i]);
+    free(small);
+    PyBuffer_Release(&kp_b);
+    PyBuffer_Release(&fr_b);
+    PyBuffer_Release(&loc_b);
+    PyBuffer_Release(&st_b);
+    return result;
+}
+
+/* chain_poses(rel float64 [P,12], first float64 [12], ex float64 [P+1,12] out, cam float64 [P+1,3] out)
+ * Global extrinsics and camera centres from relative poses (utils/utils.py:283-288):
+ * R' = R R_prev, t' = R t_prev + t, centre = -R'^T t'; sums taken left to right. */
+static PyObject *chain_poses(PyObject *Py_UNUSED(self), PyObject *args)
+{
+    Py_buffer rel_b, first_b, ex_b, cam_b;
+    if (!PyArg_ParseTuple(args, "y*y*w*w*", &rel_b, &first_b, &ex_b, &cam_b))
+        return NULL;
+    PyObject *result = NULL;
+    const Py_ssize_t P = rel_b.len / (Py_ssize_t)(12 * sizeof(double));
+    if (first_b.len < (Py_ssize_t)(12 * sizeof(double)) || ex_b.len < (P + 1) * (Py_ssize_t)(12 * sizeof(double)) ||
+        cam_b.len < (P + 1) * (Py_ssize_t)(3 * sizeof(double))) {
+        PyErr_SetString(PyExc_ValueError, "chain_poses: output buffers too small");
+        goto done;
+    }
+    {
+        const double *rel = (const double *)rel_b.buf, *first = (const double *)first_b.buf;
+        double *ex = (double *)ex_b.buf, *cam = (double *)cam_b.buf;
+        for (int i = 0; i < 12; ++i)
+            ex[i] = first[i];
+        cam[0] = cam[1] = cam[2] = 0.0;
+        for (Py_ssize_t p = 0; p < P; ++p) {
+            const double *r = rel + 12 * p, *e = ex + 12 * p;
+            double *o = ex + 12 * (p + 1), *c = cam + 3 * (p + 1);
+            for (int i = 0; i < 3; ++i) {
+                for (int j = 0; j < 3; ++j)
+                    o[4 * i + j] = r[4 * i] * e[j] + r[4 * i + 1] * e[4 + j] + r[4 * i + 2] * e[8 + j];
+                o[4 * i + 3] = (r[4 * i] * e[3] + r[4 * i + 1] * e[7] + r[4 * i + 2] * e[11]) + r[4 * i + 3];
+            }
+            for (int j = 0; j < 3; ++j)
+                c[j] = -o[j] * o[3] - o[4 + j] * o[7] - o[8 + j] * o[11];
+        }
+    }
+    result = Py_None;
+    Py_INCREF(result);
+done:
+    PyBuffer_Release(&rel_b);
+    PyBuffer_Release(&first_b);
+    PyBuffer_Release(&ex_b);
+    PyBuffer_Release(&cam_b);
+    return result;
+}
+
 static PyMethodDef methods[] = {
+    {"build_tracks", build_tracks, METH_VARARGS, "Track-point table (CSR by track) -> {track id: [(kp, (xl, xr, yl), frame), ...]}."},
+    {"chain_poses", chain_poses, METH_VARARGS, "Relative poses -> global extrinsics and camera centres."},
     {"replay_pairs", replay_pairs, METH_VARARGS,
      "Feed the inlier tables of consecutive frame pairs into the track store's containers."},
     {NULL, NULL, 0, NULL},

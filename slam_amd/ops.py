@@ -428,3 +428,28 @@ def refine_winners(K, t_right, X, Y, Z, uL, vL, uR, vR, cap, n_dev, Rt0, thresh=
                                  ctypes.c_void_p(ref_count.data_ptr()), _stream())
     _lib.check(st, "slam_refine_winners")
     return out[:n_sets], ok[:n_sets], ref_count[:n_sets]
+
+
+def track_assign(inl_rows, inl_loc, n_inl, kp_cap, first_frame=0):
+    """Track ids and the track-point table of consecutive frame pairs (slam_track_assign).
+
+    inl_rows [cap,4] int32, inl_loc [cap,6] float32: dense inlier tables; n_inl [P] int32; every
+    keypoint index < kp_cap.  Returns a dict of device tensors: row_track, row_depth [cap],
+    track_start [cap+1], pt_kp, pt_frame [2 cap], pt_loc [2 cap,3], summary [8] (rows, tracks,
+    points, longest track, flags).  Nothing is synchronised."""
+    lib = _lib.load()
+    cap, P = inl_rows.shape[0], n_inl.shape[0]
+    dev = inl_rows.device
+    i32 = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    out = dict(row_track=i32(cap), row_depth=i32(cap), track_start=i32(cap + 1), pt_kp=i32(2 * cap), pt_frame=i32(2 * cap),
+               pt_loc=torch.empty((max(2 * cap, 1), 3), dtype=torch.float32, device=dev), summary=i32(8))
+    nbytes = int(lib.slam_track_assign_work_bytes(P, cap, int(kp_cap)))
+    work = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = lib.slam_track_assign(_dev(inl_rows, torch.int32, "inl_rows"), _dev(inl_loc, torch.float32, "inl_loc"),
+                               _dev(n_inl, torch.int32, "n_inl"), P, cap, int(kp_cap), int(first_frame),
+                               p(out["row_track"]), p(out["row_depth"]), p(out["track_start"]), p(out["pt_kp"]),
+                               p(out["pt_frame"]), p(out["pt_loc"]), p(out["summary"]), p(work), nbytes, _stream())
+    _lib.check(st, "slam_track_assign")
+    out["work"] = work                 # alive until the stream has run the kernels
+    return out

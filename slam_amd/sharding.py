@@ -100,19 +100,21 @@ class TableGather:
         if ws is not None and self.collective:
             gloo = dist.get_backend(group) == "gloo"
             dev = "cpu" if gloo else ws.arena.device
-            mine = torch.tensor([ws.P, ws.layout.pairs, ws.layout.rows], dtype=torch.int64, device=dev)
-            every = [torch.zeros(3, dtype=torch.int64, device=dev) for _ in range(world)]
+            mine = torch.tensor([ws.P, ws.layout.pairs, ws.layout.rows, getattr(ws, "max_nL", 0)], dtype=torch.int64, device=dev)
+            every = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(world)]
             dist.all_gather(every, mine, group=group)
             every = torch.stack(every).cpu().numpy()
             self.pairs_of = [int(v) for v in every[:, 0]]
+            self.kp_cap = int(every[:, 3].max())
             self.fixed = bool((every[:, 1] == every[0, 1]).all() and (every[:, 2] == every[0, 2]).all())
             if self.fixed and rank == 0:
                 self.recv = [torch.empty(ws.layout.nbytes, dtype=torch.uint8, device=dev) for _ in range(world)]
 
     def _shard(self, views, P):
         pose = views["pose_b" if self.pose == "pose" else "pose_a"]
+        kp_cap = getattr(self, "kp_cap", None) or getattr(self.ws, "max_nL", None) or None
         return dict(n_inl=views["n_inl"][:P], n_cons=views["n_cons"][:P], pose=pose[:P], rows=views["rows"],
-                    loc=views["loc"])
+                    loc=views["loc"], kp_cap=kp_cap)
 
     def run(self):
         """Tables of every rank on rank 0 (None elsewhere): list of dicts n_inl [P_r], n_cons [P_r],
@@ -219,6 +221,62 @@ def replay_tracks(shards, first_frame=0, first=None):
         ex, cam = chain_poses(np.stack(poses), first=first)
         db.set_ex_matrices(ex)
         db.set_ex_camera_positions(cam)
+    return db
+
+
+def replay_tracks_device(shards, first_frame=0, first=None, device=None):
+    """replay_tracks with the sequential part done on the GPU: track ids, track lengths and the
+    track-point table come from slam_track_assign over the gathered inlier tables (one pass of
+    pointer jumping and two scans instead of a walk over every row), and the result is an
+    ArrayTrackDatabase that answers the track store's getters from those arrays.  Same state as
+    replay_tracks; falls back to it when the tables hold something the kernels do not cover (two rows
+    of one pair continuing the same track).  Tables on the host (gloo rehearsal) are uploaded."""
+    from . import ops
+    from .track_database import ArrayTrackDatabase, _native
+    shards = [sh for sh in shards]
+    if device is None:
+        cuda = [sh["rows"].device for sh in shards if sh["rows"].is_cuda]
+        device = cuda[0] if cuda else torch.device("cuda", torch.cuda.current_device())
+    up = lambda t: t if t.device == device else t.to(device)
+    if len(shards) == 1:
+        n_inl_d, rows_d, loc_d = up(shards[0]["n_inl"]), up(shards[0]["rows"]), up(shards[0]["loc"])
+    else:
+        # the valid rows of every shard, back to back (one size read per shard)
+        totals = [int(sh["n_inl"].sum().item()) for sh in shards]
+        n_inl_d = torch.cat([up(sh["n_inl"]) for sh in shards])
+        rows_d = torch.cat([up(sh["rows"][:t]) for sh, t in zip(shards, totals)])
+        loc_d = torch.cat([up(sh["loc"][:t]) for sh, t in zip(shards, totals)])
+    n_inl_d = n_inl_d.to(torch.int32).contiguous()
+    rows_d, loc_d = rows_d.contiguous(), loc_d.contiguous()
+    P = int(n_inl_d.shape[0])
+    kp_caps = [sh.get("kp_cap") for sh in shards]
+    if P == 0 or rows_d.shape[0] == 0:
+        return replay_tracks(shards, first_frame, first)
+    if any(k is None for k in kp_caps):
+        kp_cap = int(torch.maximum(rows_d[:, 0].max(), rows_d[:, 2].max()).item()) + 1
+    else:
+        kp_cap = max(int(k) for k in kp_caps)
+    out = ops.track_assign(rows_d, loc_d, n_inl_d, kp_cap, first_frame)
+    summary = out["summary"].cpu().numpy()
+    T, n_tracks, N, longest, flags = (int(v) for v in summary[:5])
+    if flags:
+        return replay_tracks(shards, first_frame, first)
+    host = lambda t, n: t[:n].cpu().numpy()
+    db = ArrayTrackDatabase(first_frame, n_inl_d.cpu().numpy(), host(out["row_track"], T), host(out["row_depth"], T),
+                            host(out["track_start"], n_tracks + 1), host(out["pt_kp"], N), host(out["pt_frame"], N),
+                            host(out["pt_loc"], N), max_length=longest)
+    n_inl = np.concatenate([sh["n_inl"].cpu().numpy() for sh in shards]).astype(np.int64)
+    n_cons = np.concatenate([sh["n_cons"].cpu().numpy() for sh in shards]).astype(np.int64)
+    db.set_frame_records(np.where(n_cons > 0, n_inl / np.maximum(n_cons, 1), 0.0), n_inl.astype(np.float64))
+    poses = np.ascontiguousarray(np.concatenate([sh["pose"].cpu().numpy().reshape(-1, 12) for sh in shards]))
+    if _native is not None:
+        ex, cam = np.empty((P + 1, 3, 4)), np.empty((P + 1, 3))
+        start = np.hstack([np.eye(3), np.zeros((3, 1))]) if first is None else np.asarray(first, dtype=np.float64)
+        _native.chain_poses(poses, np.ascontiguousarray(start.reshape(12)), ex, cam)
+    else:
+        ex, cam = chain_poses(poses.reshape(-1, 3, 4), first=first)
+    db.set_ex_matrices(ex)
+    db.set_ex_camera_positions(cam)
     return db
 
 

@@ -327,3 +327,295 @@ class TrackDatabase:
             elif a[k] != b[k]:
                 return False
         return True
+
+
+# ---------------------------------------------------------------------------------------------
+class _LazyMap:
+    """Read-only mapping whose values are made on demand (dict-like enough for the consumers of
+    get_trackIds / get_frameIds: len, iteration, indexing, membership, keys/values/items, ==)."""
+
+    def __init__(self, keys, make):
+        self._keys, self._make = keys, make
+
+    def __len__(self):
+        return len(self._keys)
+
+    def __iter__(self):
+        return iter(self._keys)
+
+    def __contains__(self, k):
+        return k in self._keys
+
+    def __getitem__(self, k):
+        if k not in self._keys:
+            raise KeyError(k)
+        return self._make(k)
+
+    def get(self, k, default=None):
+        return self._make(k) if k in self._keys else default
+
+    def keys(self):
+        return self._keys
+
+    def values(self):
+        return (self._make(k) for k in self._keys)
+
+    def items(self):
+        return ((k, self._make(k)) for k in self._keys)
+
+    def __eq__(self, other):
+        try:
+            return len(self) == len(other) and all(k in other and other[k] == self._make(k) for k in self._keys)
+        except TypeError:
+            return NotImplemented
+
+
+def _lazy_container(name):
+    slot = "_store" + name
+
+    def get(self):
+        if self._arrays is not None:
+            self._materialize()
+        return self.__dict__[slot]
+
+    def put(self, value):
+        self.__dict__[slot] = value
+
+    return property(get, put)
+
+
+class ArrayTrackDatabase(TrackDatabase):
+    """The track store answered from flat arrays (what slam_track_assign produces on the GPU)
+    instead of a dict of lists of tuples: same getters, same answers, same pickle -- but nothing is
+    built per track point until somebody asks for it.
+
+    Arrays (host numpy): n_inl [P] inlier rows per pair; row_track, row_depth [T] track id and
+    position-in-track minus one of every inlier row; track_start [n_tracks + 1] and the point table
+    pt_kp, pt_frame [N], pt_loc [N,3] float32 laid out track after track, points in frame order.
+    Pair p is frames (first_frame + p, first_frame + p + 1).
+
+    Reading methods work on the arrays.  The dict-of-lists containers of the reference's schema
+    (models/TrackDatabase.py:17-20) are built on first use of `_tracks`, `_frame_ids` or
+    `_last_insertions` -- serialize(), ==, or any method that adds rows -- and from then on the
+    object behaves exactly like the plain TrackDatabase it has become."""
+
+    _tracks = _lazy_container("_tracks")
+    _frame_ids = _lazy_container("_frame_ids")
+    _last_insertions = _lazy_container("_last_insertions")
+
+    def __init__(self, first_frame, n_inl, row_track, row_depth, track_start, pt_kp, pt_frame, pt_loc, max_length=None):
+        self._arrays = None
+        super().__init__()
+        n_inl = np.ascontiguousarray(n_inl, dtype=np.int64)
+        T = int(n_inl.sum())
+        n_tracks = int(np.count_nonzero(np.asarray(row_depth[:T]) == 0))
+        a = dict(first=int(first_frame), P=int(n_inl.shape[0]), n_inl=n_inl,
+                 off=np.concatenate([[0], np.cumsum(n_inl)]).astype(np.int64),
+                 row_track=np.ascontiguousarray(row_track[:T], dtype=np.int32),
+                 row_depth=np.ascontiguousarray(row_depth[:T], dtype=np.int32),
+                 track_start=np.ascontiguousarray(track_start[:n_tracks + 1], dtype=np.int32))
+        N = int(a["track_start"][n_tracks]) if n_tracks else 0
+        a["pt_kp"] = np.ascontiguousarray(pt_kp[:N], dtype=np.int32)
+        a["pt_frame"] = np.ascontiguousarray(pt_frame[:N], dtype=np.int32)
+        a["pt_loc"] = np.ascontiguousarray(pt_loc[:N], dtype=np.float32).reshape(N, 3)
+        a["n_tracks"], a["T"] = n_tracks, T
+        self._track_cache = {}
+        self._next_free_trackId = n_tracks
+        self._num_tracks = n_tracks
+        lengths = np.diff(a["track_start"]) if n_tracks else np.zeros(0, np.int64)
+        self._max_length = int(lengths.max() if max_length is None and n_tracks else (max_length or 0))
+        self._min_length = 2 if T else np.inf       # every track starts with two points (models/TrackDatabase.py:67,76)
+        with_rows = np.flatnonzero(n_inl)
+        # the reference refreshes the frame count whenever a row is added: the frames registered
+        # up to the last pair that had rows (models/TrackDatabase.py:74)
+        self._num_frames = int(with_rows[-1]) + 2 if with_rows.size else 0
+        self._arrays = a
+
+    # -- switching to the dict form ------------------------------------------------------------
+    def _materialize(self):
+        a, self._arrays = self._arrays, None
+        n = a["n_tracks"]
+        if _native is not None:
+            tracks = _native.build_tracks(a["pt_kp"], a["pt_frame"], a["pt_loc"], a["track_start"], n)
+        else:
+            kp, fr, loc, st = a["pt_kp"].tolist(), a["pt_frame"].tolist(), a["pt_loc"].astype(np.float64).tolist(), \
+                a["track_start"].tolist()
+            tracks = {t: [(kp[i], tuple(loc[i]), fr[i]) for i in range(st[t], st[t + 1])] for t in range(n)}
+        first, P, off = a["first"], a["P"], a["off"]
+        frame_ids = {}
+        for f in range(P + 1 if P else 0):
+            frame_ids[first + f] = self._frame_set(a, f)
+        last = {1: {}, 0: {}}
+        for q in (P - 2, P - 1):
+            if q < 0:
+                continue
+            rows = slice(int(off[q]), int(off[q + 1]))
+            tid = a["row_track"][rows]
+            cur_left = a["pt_kp"][a["track_start"][tid] + 1 + a["row_depth"][rows]]
+            last[(first + q + 1) % 2] = dict(zip(cur_left.tolist(), tid.tolist()))     # later rows overwrite earlier
+        self._tracks, self._frame_ids, self._last_insertions = tracks, frame_ids, last
+        self._track_cache = {}
+
+    @staticmethod
+    def _frame_set(a, f):
+        """Tracks with a point in the f-th frame of the run: the rows of the pair that ends there,
+        and the tracks the pair that starts there opens."""
+        off, out = a["off"], set()
+        if f >= 1:
+            out.update(a["row_track"][int(off[f - 1]):int(off[f])].tolist())
+        if f < a["P"]:
+            s = slice(int(off[f]), int(off[f + 1]))
+            out.update(a["row_track"][s][a["row_depth"][s] == 0].tolist())
+        return out
+
+    def _mutating(name):                                     # noqa: N805 -- class-body helper
+        base = getattr(TrackDatabase, name)
+
+        def method(self, *args, **kw):
+            if self._arrays is not None:
+                self._materialize()
+            return base(self, *args, **kw)
+        method.__name__ = name
+        method.__doc__ = base.__doc__
+        return method
+
+    for _n in ("prepare_to_next_pair", "get_kp_trackId", "generate_new_track_id", "add_to_track",
+               "update_tracks_from_frame", "update_tracks_from_tables", "update_tracks_from_pair_tables", "deserialize"):
+        locals()[_n] = _mutating(_n)
+    del _n, _mutating
+
+    # -- per-frame records -----------------------------------------------------------------------
+    def _has_frame(self, frame_id):
+        a = self._arrays
+        return a["P"] > 0 and a["first"] <= frame_id <= a["first"] + a["P"]
+
+    def add_inliers_ratio(self, frame_id, ratio):
+        if self._arrays is None:
+            return super().add_inliers_ratio(frame_id, ratio)
+        assert self._has_frame(frame_id)
+        self._frame_id_to_inliers_ratio[frame_id] = ratio
+
+    def add_num_matches(self, frame_id, num_matches):
+        if self._arrays is None:
+            return super().add_num_matches(frame_id, num_matches)
+        assert self._has_frame(frame_id)
+        self._frame_id_to_num_matches[frame_id] = num_matches
+
+    def set_frame_records(self, ratios, num_matches):
+        """add_inliers_ratio / add_num_matches for every pair of the run at once (utils/utils.py:281-282)."""
+        a = self._arrays
+        frames = range(a["first"], a["first"] + a["P"])
+        self._frame_id_to_inliers_ratio.update(zip(frames, np.asarray(ratios, dtype=np.float64).tolist()))
+        self._frame_id_to_num_matches.update(zip(frames, np.asarray(num_matches, dtype=np.float64).tolist()))
+
+    # -- queries from the arrays -----------------------------------------------------------------
+    def get_track_data(self, track_id):
+        a = self._arrays
+        if a is None:
+            return super().get_track_data(track_id)
+        track = self._track_cache.get(track_id)
+        if track is None:
+            if not 0 <= track_id < a["n_tracks"]:
+                raise KeyError(track_id)
+            s = slice(int(a["track_start"][track_id]), int(a["track_start"][track_id + 1]))
+            track = [(k, tuple(l), f) for k, l, f in zip(a["pt_kp"][s].tolist(), a["pt_loc"][s].astype(np.float64).tolist(),
+                                                         a["pt_frame"][s].tolist())]
+            self._track_cache[track_id] = track
+        return track
+
+    def get_track_ids_for_frame(self, frameId):
+        a = self._arrays
+        if a is None:
+            return super().get_track_ids_for_frame(frameId)
+        return list(self._frame_set(a, frameId - a["first"])) if self._has_frame(frameId) else []
+
+    def get_frame_ids_for_track(self, trackId):
+        a = self._arrays
+        if a is None:
+            return super().get_frame_ids_for_track(trackId)
+        if not 0 <= trackId < a["n_tracks"]:
+            return []
+        return a["pt_frame"][int(a["track_start"][trackId]):int(a["track_start"][trackId + 1])].tolist()
+
+    def get_feature_locations(self, frameId, trackId):
+        a = self._arrays
+        if a is None:
+            return super().get_feature_locations(frameId, trackId)
+        if not 0 <= trackId < a["n_tracks"]:
+            return None
+        s0, s1 = int(a["track_start"][trackId]), int(a["track_start"][trackId + 1])
+        hit = np.flatnonzero(a["pt_frame"][s0:s1] == frameId)
+        return tuple(a["pt_loc"][s0 + int(hit[0])].astype(np.float64).tolist()) if hit.size else None
+
+    def get_mean_track_length(self):
+        a = self._arrays
+        if a is None:
+            return super().get_mean_track_length()
+        if not self._num_tracks:
+            return 0
+        self._mean_track_length = int(a["track_start"][a["n_tracks"]]) / self._num_tracks
+        return self._mean_track_length
+
+    def get_mean_frame_links(self):
+        a = self._arrays
+        if a is None:
+            return super().get_mean_frame_links()
+        if not self._num_frames:
+            return 0
+        # a frame holds the rows of the pair ending there plus the tracks opened by the pair starting there
+        links = a["T"] + a["n_tracks"]
+        self._mean_frame_links = links / self._num_frames
+        return self._mean_frame_links
+
+    def get_random_track_of_length(self, length):
+        a = self._arrays
+        if a is None:
+            return super().get_random_track_of_length(length)
+        pool = np.flatnonzero(np.diff(a["track_start"]) >= length).tolist()
+        if not pool:
+            return None
+        tid = random.choice(pool)                  # one draw from a pool of the same size and order as the reference's
+        return tid, self.get_track_data(tid)
+
+    def get_all_tracks_of_length(self, length):
+        a = self._arrays
+        if a is None:
+            return super().get_all_tracks_of_length(length)
+        return [(t, self.get_track_data(t)) for t in np.flatnonzero(np.diff(a["track_start"]) == length).tolist()]
+
+    def calculate_connectivity_data(self):
+        a = self._arrays
+        if a is None:
+            return super().calculate_connectivity_data()
+        if a["first"] != 0:
+            raise KeyError(0)                      # the reference walks frames 0 .. num_frames-1 (models/TrackDatabase.py:247-249)
+        x = np.arange(self._num_frames)
+        y = np.zeros_like(x)
+        m = max(len(y) - 1, 0)
+        y[:m] = a["n_inl"][:m]                    # tracks present in frames i and i+1 = rows of pair i
+        return x, y
+
+    def get_track_length_data(self):
+        a = self._arrays
+        if a is None:
+            return super().get_track_length_data()
+        return np.diff(a["track_start"]).astype(np.int64)
+
+    def get_trackIds(self):
+        a = self._arrays
+        if a is None:
+            return super().get_trackIds()
+        return _LazyMap(range(a["n_tracks"]), self.get_track_data)
+
+    def get_frameIds(self):
+        a = self._arrays
+        if a is None:
+            return super().get_frameIds()
+        frames = range(a["first"], a["first"] + a["P"] + 1) if a["P"] else range(0)
+        return _LazyMap(frames, lambda f: self._frame_set(a, f - a["first"]))
+
+    def get_track_locations_in_segment(self, track_id, frame_id_start, frame_id_stop):
+        return [pt for _, pt, fid in self.get_track_data(track_id) if frame_id_start < fid <= frame_id_stop + 1]
+
+    def get_all_points_in_track(self, track_id):
+        return [pt for _, pt, _ in self.get_track_data(track_id)]

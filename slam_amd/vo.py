@@ -13,7 +13,7 @@ import torch
 
 from . import frontend, pipeline
 from .constants import PIXEL_THRESH, STEREO_ROW_THRESH, VO_MAX_ITERATIONS
-from .sharding import TableGather, chain_poses, replay_tracks
+from .sharding import TableGather, chain_poses, replay_tracks, replay_tracks_device
 from .track_database import TrackDatabase
 
 
@@ -64,7 +64,7 @@ def track_camera_device(frames, seed=6, n_hyp=VO_MAX_ITERATIONS, cameras=None, t
     """(camera_positions [F,3], TrackDatabase) with the whole RANSAC on the device as well:
     per pair `n_hyp` minimal samples from a generator keyed by (seed, pair, hypothesis), P3P,
     supporter counts, the reference's stopping rule, refinement of the winner, inlier tables
-    (pipeline.FrontEnd.run_ransac).  Only the track database is replayed on the host.  The
+    (pipeline.FrontEnd.run_ransac).  The track store is an ArrayTrackDatabase built from device-made track ids.  The
     draws differ from the reference's process-global `random` stream, which chains the frames
     one after the other; everything downstream of the draws follows utils/utils.py:413-464."""
     k, m1, m2 = cameras if cameras is not None else frontend.read_cameras()
@@ -77,7 +77,8 @@ def track_camera_device(frames, seed=6, n_hyp=VO_MAX_ITERATIONS, cameras=None, t
     torch.cuda.synchronize()
     found = ws.found.cpu().numpy()[:ws.P]
     assert found.all(), f"RANSAC Couldn't find a transformation from frame {int(np.argmin(found))} to the next one"
-    db = replay_tracks(TableGather(ws, pose="pose").run(), first=m1)
+    # track ids and the track-point table are made on the device too; the store answers from arrays
+    db = replay_tracks_device(TableGather(ws, pose="pose").run(), first=m1)
     return np.asarray(db.camera_positions), db
 
 

@@ -184,6 +184,29 @@ def test_full_sequence_length_in_one_batch(device):
     assert db.get_num_frames() == n_frames
     lengths = db.get_track_length_data()
     assert int((lengths - 1).sum()) == int(n_inl.sum())
+    # the same store with the sequential part done on the device: arrays first, dicts on demand
+    import time
+    from slam_amd.track_database import ArrayTrackDatabase
+    t0 = time.perf_counter()
+    dbd = sharding.replay_tracks_device(sharding.TableGather(ws, pose="pose").run(), first=m1)
+    t_dev = time.perf_counter() - t0
+    assert isinstance(dbd, ArrayTrackDatabase) and dbd._arrays is not None
+    assert (dbd.get_num_tracks(), dbd.get_num_frames(), dbd.get_max_track(), dbd.get_min_track()) == \
+        (db.get_num_tracks(), db.get_num_frames(), db.get_max_track(), db.get_min_track())
+    assert np.array_equal(dbd.get_track_length_data(), lengths)
+    for f in (0, 1, P // 2, P - 1, P):
+        ids = dbd.get_track_ids_for_frame(f)
+        assert sorted(ids) == sorted(db.get_track_ids_for_frame(f))
+        for t in ids[::97]:
+            assert dbd.get_track_data(t) == db.get_track_data(t)
+    assert dbd.get_mean_track_length() == db.get_mean_track_length()
+    assert dbd.get_mean_frame_links() == db.get_mean_frame_links()
+    assert np.allclose(dbd.ex_matrices, db.ex_matrices, rtol=0, atol=1e-9)
+    assert dbd._arrays is not None
+    print(f"device replay of {P} pairs, {int(n_inl.sum())} rows: {1e3 * t_dev:.1f} ms")
+    dbd.set_ex_matrices(db.ex_matrices)
+    dbd.set_ex_camera_positions(db.camera_positions)
+    assert dbd == db                                               # materialises the dict form
     # dead reckoning over 3.6 km: the chained positions drift with the accumulated yaw error, a few per cent of the path
     path = 0.8 * P
     assert np.abs(np.asarray(db.camera_positions) - sharding.chain_poses(gt, first=m1)[1]).max() < 0.1 * path

@@ -138,3 +138,76 @@ def test_pickle_written_here_has_the_reference_schema(tmp_path):
                       "frame_id_to_inliers_ratio", "ex_camera_positions", "ex_matrices", "frame_id_to_num_matches"}
     back = TrackDatabase(path)
     _check(back, "mini", "pickle")
+
+
+# ---- the array-backed store -----------------------------------------------------------------------
+from slam_amd.track_database import ArrayTrackDatabase       # noqa: E402
+from trackdb_state import arrays_from_rows, chain_tables      # noqa: E402
+
+
+def _array_db(first, rows, loc, n_inl):
+    a = arrays_from_rows(first, rows, loc, n_inl)
+    return ArrayTrackDatabase(first, n_inl, a["row_track"], a["row_depth"], a["track_start"], a["pt_kp"], a["pt_frame"],
+                              a["pt_loc"], max_length=a["longest"])
+
+
+def test_array_backed_store_answers_like_the_reference():
+    """Getters straight from the arrays (nothing materialised), then the dict form on demand."""
+    first, rows, loc, n_inl, n_cons = _inputs("mini")
+    db = _array_db(first, rows, loc, n_inl)
+    db.set_frame_records(np.where(n_cons > 0, n_inl / np.maximum(n_cons, 1), 0.0), n_inl.astype(np.float64))
+    want = _want("mini")
+    got_q = query_arrays(db)
+    assert db._arrays is not None, "a getter built the dict form"
+    assert_same(got_q, {k: v for k, v in want.items() if k.startswith("q_")}, "mini/array getters")
+    assert_same(state_arrays(db), {k: v for k, v in want.items() if not k.startswith("q_")}, "mini/array state")
+    assert db._arrays is None                                  # the state comparison reads the dicts
+    assert_same(query_arrays(db), {k: v for k, v in want.items() if k.startswith("q_")}, "mini/after materialising")
+
+
+@pytest.mark.parametrize("first,n_pairs,seed", [(0, 40, 1), (5, 33, 2), (0, 1, 3), (0, 9, 4)])
+def test_array_backed_store_equals_the_row_walk(first, n_pairs, seed, tmp_path):
+    rows, loc, n_inl = chain_tables(n_pairs, 90, seed)
+    want = TrackDatabase()
+    off = 0
+    for p, m in enumerate(n_inl.tolist()):
+        want.update_tracks_from_tables(first + p, rows[off:off + m], loc[off:off + m])
+        off += m
+    db = _array_db(first, rows, loc, n_inl)
+    # every getter, before anything is materialised
+    for f in range(first - 1, first + n_pairs + 3):
+        assert sorted(db.get_track_ids_for_frame(f)) == sorted(want.get_track_ids_for_frame(f))
+    assert len(db.get_frameIds()) == len(want.get_frameIds()) and list(db.get_frameIds()) == list(want.get_frameIds())
+    assert db.get_frameIds() == want.get_frameIds() and db.get_trackIds() == want.get_trackIds()
+    for t in list(want.get_trackIds())[::7] + [10 ** 6]:
+        if t in want.get_trackIds():
+            assert db.get_track_data(t) == want.get_track_data(t)
+            assert [type(x) for x in db.get_track_data(t)[0]] == [type(x) for x in want.get_track_data(t)[0]]
+            assert db.get_all_points_in_track(t) == want.get_all_points_in_track(t)
+        assert db.get_frame_ids_for_track(t) == want.get_frame_ids_for_track(t)
+        assert db.get_feature_locations(first + 2, t) == want.get_feature_locations(first + 2, t)
+    assert (db.get_num_tracks(), db.get_num_frames(), db.get_max_track(), db.get_min_track()) == \
+        (want.get_num_tracks(), want.get_num_frames(), want.get_max_track(), want.get_min_track())
+    assert db.get_mean_track_length() == want.get_mean_track_length()
+    assert db.get_mean_frame_links() == want.get_mean_frame_links()
+    assert np.array_equal(db.get_track_length_data(), want.get_track_length_data())
+    assert db.get_tracks_in_bundle_window(first, first + 4) == want.get_tracks_in_bundle_window(first, first + 4)
+    for L in (2, 3, 5):
+        assert db.get_all_tracks_of_length(L) == want.get_all_tracks_of_length(L)
+        import random
+        random.seed(L)
+        a = db.get_random_track_of_length(L)
+        random.seed(L)
+        assert a == want.get_random_track_of_length(L)
+    if first == 0:
+        assert np.array_equal(db.calculate_connectivity_data()[1], want.calculate_connectivity_data()[1])
+    assert db._arrays is not None
+    # the pickle is the plain schema, loadable by the plain class; the object itself has become a plain store
+    path = str(tmp_path / "a.pkl")
+    db.serialize(path)
+    assert TrackDatabase(path) == want and db == want
+    # ... and keeps working as one: more rows continue the tracks
+    more_rows, more_loc, more_n = chain_tables(3, 90, seed + 100, empty_every=0)
+    for d in (db, want):
+        d.update_tracks_from_pair_tables(first + n_pairs, more_rows, more_loc, more_n)
+    assert db == want

@@ -81,3 +81,66 @@ def assert_same(got, want, what=""):
         assert k in got, f"{what}: {k} missing"
         g = got[k]
         assert g.shape == v.shape and np.array_equal(g, v), f"{what}: {k} differs"
+
+
+def arrays_from_rows(first_frame, rows, loc, n_inl):
+    """The flat-array form of the track store (what the device's track assignment emits), derived
+    on the host by walking the rows the way models/TrackDatabase.py:34-76,171-184 does.  Valid for
+    tables where no two rows of a pair share prev_left.  Returns a dict of numpy arrays."""
+    rows, loc = np.asarray(rows), np.asarray(loc, dtype=np.float32)
+    T = int(np.sum(n_inl))
+    row_track = np.zeros(T, np.int32)
+    row_depth = np.zeros(T, np.int32)
+    last = {}
+    n_tracks, g = 0, 0
+    for p, m in enumerate(np.asarray(n_inl).tolist()):
+        cur = {}
+        for _ in range(m):
+            a, c = int(rows[g, 0]), int(rows[g, 2])
+            if a in last:
+                row_track[g], row_depth[g] = last[a][0], last[a][1] + 1
+            else:
+                row_track[g], row_depth[g] = n_tracks, 0
+                n_tracks += 1
+            cur[c] = (int(row_track[g]), int(row_depth[g]))
+            g += 1
+        last = cur
+    length = np.zeros(n_tracks, np.int64)
+    np.maximum.at(length, row_track, row_depth + 2)
+    track_start = np.concatenate([[0], np.cumsum(length)]).astype(np.int32)
+    N = int(track_start[-1])
+    pt_kp, pt_frame, pt_loc = np.zeros(N, np.int32), np.zeros(N, np.int32), np.zeros((N, 3), np.float32)
+    pair_of = np.repeat(np.arange(len(n_inl)), np.asarray(n_inl))
+    s = track_start[row_track] + 1 + row_depth
+    pt_kp[s], pt_frame[s], pt_loc[s] = rows[:T, 2], first_frame + pair_of + 1, loc[:T, 3:]
+    new = row_depth == 0
+    s0 = track_start[row_track[new]]
+    pt_kp[s0], pt_frame[s0], pt_loc[s0] = rows[:T, 0][new], first_frame + pair_of[new], loc[:T, :3][new]
+    return dict(row_track=row_track, row_depth=row_depth, track_start=track_start, pt_kp=pt_kp, pt_frame=pt_frame,
+                pt_loc=pt_loc, n_tracks=n_tracks, n_points=N, longest=int(length.max()) if n_tracks else 0)
+
+
+def chain_tables(n_pairs, n_kp, seed, empty_every=7, keep=0.8, full=False):
+    """Random inlier tables with real track structure and unique prev_left per pair (what the
+    front-end emits): continuations, repeated cur_left, pairs without rows."""
+    rng = np.random.default_rng(seed)
+    rows, n_inl = [], []
+    prev_cur = np.zeros(0, np.int64)
+    for p in range(n_pairs):
+        m = 0 if (empty_every and p % empty_every == empty_every - 2) else (n_kp // 2 if full else int(rng.integers(1, n_kp // 2)))
+        prev_left = rng.permutation(n_kp)[:m]                           # unique
+        cont = np.unique(prev_cur)
+        take = cont[rng.random(cont.shape[0]) < keep][:m]
+        others = np.setdiff1d(prev_left, take, assume_unique=False)
+        prev_left = np.concatenate([take, others])[:m]
+        rng.shuffle(prev_left)
+        cur_left = rng.permutation(n_kp)[:m] if full else rng.integers(0, n_kp, size=m)
+        if m > 6:
+            cur_left[5] = cur_left[2]                                   # two rows end on one keypoint: the later one is continued
+        r = np.stack([prev_left, rng.integers(0, n_kp, m), cur_left, rng.integers(0, n_kp, m)], axis=1)
+        rows.append(r.astype(np.int32).reshape(-1, 4))
+        n_inl.append(m)
+        prev_cur = cur_left
+    rows = np.concatenate(rows)
+    loc = rng.uniform(0, 1226, (rows.shape[0], 6)).astype(np.float32)
+    return rows, loc, np.asarray(n_inl, np.int64)
