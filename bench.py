@@ -50,6 +50,10 @@ def parse():
                          "resident ones; larger batches amortise launch tails, 127 / 255 / 1023 work as well)")
     ap.add_argument("--kp", type=int, default=2000, help="keypoints per image")
     ap.add_argument("--hyp", type=int, default=10000, help="pose hypotheses per pair")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling (BASELINE configs[2]/[3]): ONE sequence of --frames frames sharded by frame range "
+                         "over the ranks, hypotheses made on the device, tables gathered to rank 0, track store built there")
+    ap.add_argument("--frames", type=int, default=4541, help="frames of the full sequence (--strong and the full_sequence block)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=128, help="frame pairs timed on the CPU oracle")
     return ap.parse_args()
@@ -89,6 +93,100 @@ def cpu_baseline(seq, Rt_host, n_pairs, threads):
     return n_pairs / dt, dt
 
 
+def sequence_run(a, rank, world, dev, multi, backend, steps, warmup):
+    """One KITTI-00-sized sequence (a.frames frames x a.kp keypoints) sharded by contiguous frame range over
+    the ranks: per step every rank runs the whole front-end with the device-side RANSAC (1000 hypotheses per
+    pair, the VO loop's max_iterations) on its pairs and the inlier tables are gathered to rank 0.  After the
+    timed steps rank 0 builds the track store from the gathered tables (track ids on its GPU, array-backed
+    store) -- the sequential tail, timed on its own.  Returns (dt over `steps`, info dict or None)."""
+    import torch
+    import torch.distributed as dist
+    from slam_amd import pipeline, sharding
+    from slam_amd.synthetic import SyntheticSequence, read_cameras
+    t0 = time.perf_counter()
+    seq = SyntheticSequence(a.kp, a.frames)               # generated whole on every rank: frame f depends on frames < f
+    t_gen = time.perf_counter() - t0
+    s, e = sharding.shard_pairs(a.frames, world)[rank]
+    k, m1, m2 = read_cameras()
+    fe = pipeline.FrontEnd(k, m1, m2, row_thresh=2.0, ratio_thresh=1.0, pix_thresh=2.0)
+    tb = pipeline.FrameTables.from_frames(seq.frames[s:e + 1], dev)
+    P = e - s
+    cap_rows = P * int(np.diff(tb.offL).max())
+    tp, tr = sharding.agree_table_shape(P, cap_rows, device=dev) if multi else (P, cap_rows)
+    lanes = []
+    for _ in range(2 if multi else 1):                    # two workspaces: the gather of one step under the kernels of the next
+        w = fe.prepare(tb, n_hyp=1000, table_pairs=tp, table_rows=tr)
+        fe.prepare_ransac(w)
+        lanes.append([w, torch.cuda.Stream(), sharding.TableGather(w, world, rank, pose="pose", collective=multi), None])
+    side = torch.cuda.Stream()
+    n = [0]
+
+    def step():
+        lane = lanes[n[0] % len(lanes)]
+        n[0] += 1
+        w, launch, gather, sent = lane
+        with torch.cuda.stream(launch):
+            if sent is not None:
+                launch.wait_event(sent)
+            fe.run_ransac(w, 6)
+            ready = launch.record_event()
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            lane[3] = None
+            res = gather.run()
+            lane[3] = side.record_event()
+        return res
+
+    def fence():
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(warmup, 1)):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        shards = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if multi:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return dt, None
+    # the sequential tail on rank 0: the track store from the gathered tables
+    sharding.replay_tracks_device(shards, first=m1)        # warm (module load, allocator)
+    t0 = time.perf_counter()
+    db = sharding.replay_tracks_device(shards, first=m1)
+    ids = db.get_track_ids_for_frame(a.frames // 2)        # what bundle adjustment asks (models/BundleAdjustment.py:186-188,213-219)
+    _ = [db.get_track_data(t) for t in ids]
+    t_store = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    host_db = sharding.replay_tracks(shards, first=m1) if os.environ.get("SLAM_BENCH_HOST_REPLAY", "1") != "0" else None
+    t_host = time.perf_counter() - t0
+    n_pairs = a.frames - 1
+    info = {
+        "workload": f"one sequence of {a.frames} frames x {a.kp} keypoints, 1000 device-made hypotheses per pair, "
+                    f"frame-range shards x{world}, building the track store",
+        "gpu_ms_per_pass": 1e3 * dt / steps, "frame_pairs_per_s_gpu": n_pairs * steps / dt,
+        "track_store_ms": 1e3 * t_store,
+        "wall_ms_per_sequence": 1e3 * (dt / steps + t_store),
+        "frame_pairs_per_s_wall": n_pairs / (dt / steps + t_store),
+        "host_row_replay_ms": 1e3 * t_host if host_db is not None else None,
+        "tracks": db.get_num_tracks(), "mean_track_length": db.get_mean_track_length(), "max_track": db.get_max_track(),
+        "track_store_equals_host_replay": (bool(np.array_equal(db.get_track_length_data(), host_db.get_track_length_data()))
+                                           if host_db is not None else None),
+        "host_generate_s": t_gen, "hbm_allocated_GB": torch.cuda.max_memory_allocated() / 1e9,
+        "note": "gpu_ms_per_pass: every stage incl. RANSAC and the gather, inputs resident; track_store_ms: track ids on "
+                "the GPU, copy to the host, array-backed store answering one bundle window's queries; "
+                "host_row_replay_ms: the row-by-row replay it replaces",
+    }
+    return dt, info
+
+
 def main():
     a = parse()
     # stdout carries exactly one line, the JSON result: libraries that print to file descriptor 1
@@ -119,6 +217,28 @@ def main():
 
     from slam_amd import pipeline, sharding
     from slam_amd.synthetic import SyntheticSequence, read_cameras, seeded_hypotheses
+
+    if a.strong:
+        dt, info = sequence_run(a, rank, world, dev, multi, backend, a.steps, a.warmup)
+        if rank == 0:
+            out = {
+                "metric": "stereo frame-pairs/sec (match+triangulate+RANSAC)",
+                "value": (a.frames - 1) * a.steps / dt, "unit": "frame-pairs/s", "n_gpus": world, "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None,
+                "dtype": "fp4 MFMA (exact Hamming) matching + f64 triangulation + f32-filtered f64 scoring",
+                "data": "synthetic",
+                "config": {"workload": "configs[2]/[3]: full sequence front-end building TrackDatabase, sharded by frame range",
+                           "frames": a.frames, "keypoints_per_image": a.kp, "hypotheses_per_pair": 1000,
+                           "sharding": f"frame-range x{world}",
+                           "gather": "none" if world == 1 else "one fixed-size RCCL gather of the table arena per pass"},
+                "full_sequence": info,
+            }
+            sys.stdout.flush()
+            os.write(result_fd, (json.dumps(out) + "\n").encode())
+        if multi:
+            dist.destroy_process_group()
+        return
 
     # ---- synthetic shard of this rank ---------------------------------------
     P, N, H = a.pairs, a.kp, a.hyp
@@ -338,6 +458,14 @@ def main():
                                "add hypothesis_set_bytes_per_step / measured_h2d_GBs per step)"}
         del rawL, rawR, stage, Rt_pinned, Rt_dst
 
+    # ---- BASELINE configs[2] beside the headline: the full sequence on this GPU, track store included
+    full_info = None
+    if rank == 0 and world == 1 and not multi and os.environ.get("SLAM_BENCH_FULLSEQ", "1") != "0":
+        try:
+            _, full_info = sequence_run(a, 0, 1, dev, False, backend, 5, 1)
+        except Exception as exc:                              # never lose the headline over the side measurement
+            full_info = {"error": repr(exc)}
+
     if rank != 0:
         if multi:
             dist.destroy_process_group()
@@ -463,6 +591,7 @@ def main():
         "stage_rooflines": {"match": match_roof, "score": score_roof, "triangulate": tri_roof},
         "device_ransac": ransac_info,
         "host_fed": ingest_info,
+        "full_sequence": full_info,
     }
     if not a.no_cpu_baseline:
         threads = min(16, os.cpu_count() or 1)

@@ -317,6 +317,42 @@ done:
     return result;
 }
 
+/* track_list(pt_kp, pt_frame, pt_loc, start, stop) -> [(kp, (xl, xr, yl), frame), ...] of point slots
+ * [start, stop): one track of the table, as the list the track store keeps for it. */
+static PyObject *track_list(PyObject *Py_UNUSED(self), PyObject *args)
+{
+    Py_buffer kp_b, fr_b, loc_b;
+    Py_ssize_t a, b;
+    if (!PyArg_ParseTuple(args, "y*y*y*nn", &kp_b, &fr_b, &loc_b, &a, &b))
+        return NULL;
+    PyObject *lst = NULL;
+    const int32_t *kp = (const int32_t *)kp_b.buf, *fr = (const int32_t *)fr_b.buf;
+    const float *loc = (const float *)loc_b.buf;
+    const Py_ssize_t N = kp_b.len / (Py_ssize_t)sizeof(int32_t);
+    if (a < 0 || b < a || b > N || fr_b.len / (Py_ssize_t)sizeof(int32_t) < N ||
+        loc_b.len / (Py_ssize_t)(3 * sizeof(float)) < N) {
+        PyErr_SetString(PyExc_ValueError, "track_list: slot range outside the point table");
+        goto done;
+    }
+    lst = PyList_New(b - a);
+    for (Py_ssize_t i = a; lst && i < b; ++i) {
+        PyObject *k = PyLong_FromLong(kp[i]), *f = PyLong_FromLong(fr[i]);
+        PyObject *pt = (k && f) ? track_point(k, loc + 3 * i, f) : NULL;
+        Py_XDECREF(k);
+        Py_XDECREF(f);
+        if (!pt) {
+            Py_CLEAR(lst);
+            break;
+        }
+        PyList_SET_ITEM(lst, i - a, pt);
+    }
+done:
+    PyBuffer_Release(&kp_b);
+    PyBuffer_Release(&fr_b);
+    PyBuffer_Release(&loc_b);
+    return lst;
+}
+
 /* chain_poses(rel float64 [P,12], first float64 [12], ex float64 [P+1,12] out, cam float64 [P+1,3] out)
  * Global extrinsics and camera centres from relative poses (utils/utils.py:283-288):
  * R' = R R_prev, t' = R t_prev + t, centre = -R'^T t'; sums taken left to right. */
@@ -362,6 +398,7 @@ done:
 
 static PyMethodDef methods[] = {
     {"build_tracks", build_tracks, METH_VARARGS, "Track-point table (CSR by track) -> {track id: [(kp, (xl, xr, yl), frame), ...]}."},
+    {"track_list", track_list, METH_VARARGS, "One track of a track-point table as a list of (kp, (xl, xr, yl), frame)."},
     {"chain_poses", chain_poses, METH_VARARGS, "Relative poses -> global extrinsics and camera centres."},
     {"replay_pairs", replay_pairs, METH_VARARGS,
      "Feed the inlier tables of consecutive frame pairs into the track store's containers."},

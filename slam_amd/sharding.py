@@ -224,6 +224,23 @@ def replay_tracks(shards, first_frame=0, first=None):
     return db
 
 
+def _fetch(tensors):
+    """Device tensors -> numpy arrays through ONE pinned host buffer (asynchronous copies at the
+    link's rate, one synchronisation); the arrays are views of that buffer and keep it alive.
+    Pinned blocks come from torch's caching host allocator, so a buffer released by an earlier
+    result is reused instead of being pinned again."""
+    sizes = [t.numel() * t.element_size() for t in tensors]
+    offs = np.concatenate([[0], np.cumsum([(n + 255) // 256 * 256 for n in sizes])]).astype(np.int64)
+    buf = torch.empty(int(offs[-1]) or 1, dtype=torch.uint8, pin_memory=True)
+    views = []
+    for t, n, o in zip(tensors, sizes, offs[:-1].tolist()):
+        v = buf[o:o + n].view(t.dtype).reshape(t.shape)
+        v.copy_(t, non_blocking=True)
+        views.append(v)
+    torch.cuda.current_stream().synchronize()
+    return [v.numpy() for v in views]
+
+
 def replay_tracks_device(shards, first_frame=0, first=None, device=None):
     """replay_tracks with the sequential part done on the GPU: track ids, track lengths and the
     track-point table come from slam_track_assign over the gathered inlier tables (one pass of
@@ -261,10 +278,11 @@ def replay_tracks_device(shards, first_frame=0, first=None, device=None):
     T, n_tracks, N, longest, flags = (int(v) for v in summary[:5])
     if flags:
         return replay_tracks(shards, first_frame, first)
-    host = lambda t, n: t[:n].cpu().numpy()
-    db = ArrayTrackDatabase(first_frame, n_inl_d.cpu().numpy(), host(out["row_track"], T), host(out["row_depth"], T),
-                            host(out["track_start"], n_tracks + 1), host(out["pt_kp"], N), host(out["pt_frame"], N),
-                            host(out["pt_loc"], N), max_length=longest)
+    row_track, row_depth, track_start, pt_kp, pt_frame, pt_loc = _fetch(
+        [out["row_track"][:T], out["row_depth"][:T], out["track_start"][:n_tracks + 1], out["pt_kp"][:N],
+         out["pt_frame"][:N], out["pt_loc"][:N]])
+    db = ArrayTrackDatabase(first_frame, n_inl_d.cpu().numpy(), row_track, row_depth, track_start, pt_kp, pt_frame, pt_loc,
+                            max_length=longest)
     n_inl = np.concatenate([sh["n_inl"].cpu().numpy() for sh in shards]).astype(np.int64)
     n_cons = np.concatenate([sh["n_cons"].cpu().numpy() for sh in shards]).astype(np.int64)
     db.set_frame_records(np.where(n_cons > 0, n_inl / np.maximum(n_cons, 1), 0.0), n_inl.astype(np.float64))

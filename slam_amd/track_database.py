@@ -517,9 +517,13 @@ class ArrayTrackDatabase(TrackDatabase):
         if track is None:
             if not 0 <= track_id < a["n_tracks"]:
                 raise KeyError(track_id)
-            s = slice(int(a["track_start"][track_id]), int(a["track_start"][track_id + 1]))
-            track = [(k, tuple(l), f) for k, l, f in zip(a["pt_kp"][s].tolist(), a["pt_loc"][s].astype(np.float64).tolist(),
-                                                         a["pt_frame"][s].tolist())]
+            s0, s1 = int(a["track_start"][track_id]), int(a["track_start"][track_id + 1])
+            if _native is not None:
+                track = _native.track_list(a["pt_kp"], a["pt_frame"], a["pt_loc"], s0, s1)
+            else:
+                s = slice(s0, s1)
+                track = [(k, tuple(l), f) for k, l, f in zip(a["pt_kp"][s].tolist(), a["pt_loc"][s].astype(np.float64).tolist(),
+                                                             a["pt_frame"][s].tolist())]
             self._track_cache[track_id] = track
         return track
 

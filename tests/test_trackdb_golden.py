@@ -165,8 +165,13 @@ def test_array_backed_store_answers_like_the_reference():
     assert_same(query_arrays(db), {k: v for k, v in want.items() if k.startswith("q_")}, "mini/after materialising")
 
 
+@pytest.mark.parametrize("native", [True, False])
 @pytest.mark.parametrize("first,n_pairs,seed", [(0, 40, 1), (5, 33, 2), (0, 1, 3), (0, 9, 4)])
-def test_array_backed_store_equals_the_row_walk(first, n_pairs, seed, tmp_path):
+def test_array_backed_store_equals_the_row_walk(first, n_pairs, seed, native, tmp_path, monkeypatch):
+    if not native:
+        monkeypatch.setattr(track_database, "_native", None)      # the pure-Python forms of the same containers
+    elif track_database._native is None:
+        pytest.skip("C helper not built")
     rows, loc, n_inl = chain_tables(n_pairs, 90, seed)
     want = TrackDatabase()
     off = 0
