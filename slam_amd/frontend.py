@@ -28,6 +28,14 @@ from .types import keypoints_to_array
 random.seed(SEED)   # utils/utils.py:13 seeds the global stream at import
 
 _CAMERAS = None
+_NUM_FRAMES = 2560          # the frame count the reference hard-codes (utils/utils.py:241)
+
+
+def set_sequence_length(num_of_frames=2560):
+    """How many frames track_camera_for_many_images() walks when its caller passes none (the
+    reference's callers pass nothing: models/TrajectorySolver.py:140)."""
+    global _NUM_FRAMES
+    _NUM_FRAMES = int(num_of_frames)
 
 
 def set_cameras(k, m1, m2):
@@ -388,7 +396,7 @@ def ransac_on_arrays(X, uvL, uvR, intrinsic_matrix, right_camera_matrix, thresh=
 
 
 # --------------------------------------------------------------------------- VO loop
-def track_camera_for_many_images(thresh=1, matcher=None, num_of_frames=2560, cameras=None):
+def track_camera_for_many_images(thresh=1, matcher=None, num_of_frames=None, cameras=None):
     """Frame-by-frame visual odometry building the track database (utils/utils.py:236-294).
 
     The reference constructs its own Matcher on the KITTI images and hard-codes 2560
@@ -397,6 +405,8 @@ def track_camera_for_many_images(thresh=1, matcher=None, num_of_frames=2560, cam
     # The loop allocates tens of thousands of small acyclic objects per frame (DMatch, KeyPoint,
     # tuples) on top of a heap that keeps growing (the matcher's cache, the track store): the
     # cyclic collector would rescan all of it again and again for nothing to free.
+    if num_of_frames is None:
+        num_of_frames = _NUM_FRAMES
     gc_was_on = gc.isenabled()
     gc.disable()
     try:

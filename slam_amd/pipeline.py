@@ -34,8 +34,10 @@ class FrameTables:
     """
 
     def __init__(self, descL, descR, xL, yL, xR, yR, offL, offR, desc_bytes):
-        self.descL, self.descR = descL, descR
-        self.xL, self.yL, self.xR, self.yR = xL, yL, xR, yR
+        # a table without a single row still gets an address the library can be handed (one unused row)
+        ne = lambda t: t if t.shape[0] else torch.zeros((1,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        self.descL, self.descR = ne(descL), ne(descR)
+        self.xL, self.yL, self.xR, self.yR = ne(xL), ne(yL), ne(xR), ne(yR)
         self.offL = np.asarray(offL, dtype=np.int64)
         self.offR = np.asarray(offR, dtype=np.int64)
         self.desc_bytes = int(desc_bytes)
@@ -76,6 +78,59 @@ class FrameTables:
         offR = np.concatenate([[0], np.cumsum([f.descR.shape[0] for f in frames])])
         return cls(table([f.descL for f in frames]), table([f.descR for f in frames]), col("kpL", 0), col("kpL", 1),
                    col("kpR", 0), col("kpR", 1), offL, offR, D)
+
+
+    @classmethod
+    def from_detector_output(cls, per_frame, device):
+        """Ingestion of what a detector hands over, frame by frame: per_frame[i] =
+        ((keypoints_left, descriptors_left), (keypoints_right, descriptors_right)), exactly the two
+        pairs `algo.detectAndCompute` returns for a stereo frame and the matcher cache keeps under
+        LEFT / RIGHT (models/Matcher.py:116-119).  keypoints: a sequence of objects with `.pt`
+        (cv2.KeyPoint) or an [N,2] array; descriptors: [N,D] uint8 -- ORB 32 bytes, AKAZE 61 -- or
+        [N,128|64] float32, or None for an image without keypoints (cv2 returns None there)."""
+        from .types import keypoints_to_array
+
+        class _Frame:
+            __slots__ = ("kpL", "kpR", "descL", "descR")
+
+        width = dtype = None
+        for sides in per_frame:
+            for _, d in sides:
+                if d is not None and len(d):
+                    d = np.asarray(d)
+                    if d.ndim != 2:
+                        raise ValueError("descriptors must be [N, D]")
+                    if width is None:
+                        width, dtype = d.shape[1], (np.float32 if d.dtype.kind == "f" else np.uint8)
+                    elif d.shape[1] != width:
+                        raise ValueError(f"descriptor widths differ: {width} vs {d.shape[1]}")
+        if width is None:
+            raise ValueError("no descriptors in any frame")
+        frames = []
+        for (kl, dl), (kr, dr) in per_frame:
+            f = _Frame()
+            for side, k, d in (("L", kl, dl), ("R", kr, dr)):
+                xy = keypoints_to_array(k) if k is not None and len(k) else np.zeros((0, 2), np.float32)
+                desc = np.ascontiguousarray(d, dtype=dtype) if d is not None and len(d) else np.zeros((0, width), dtype)
+                if xy.shape[0] != desc.shape[0]:
+                    raise ValueError(f"{xy.shape[0]} keypoints but {desc.shape[0]} descriptors")
+                setattr(f, "kp" + side, xy)
+                setattr(f, "desc" + side, desc)
+            frames.append(f)
+        return cls.from_frames(frames, device)
+
+    @classmethod
+    def from_matcher_cache(cls, cache, frame_ids, device):
+        """The same from a Matcher's cache dict (models/Matcher.py:51,118-119; also in the serialised
+        form of get_matcher_cache, keypoints as dicts): frames in the order of frame_ids."""
+        from .constants import LEFT, RIGHT
+
+        def side(entry):
+            kps, dsc = entry
+            if len(kps) and isinstance(kps[0], dict):
+                kps = np.array([k["pt"] for k in kps], dtype=np.float32).reshape(-1, 2)
+            return kps, dsc
+        return cls.from_detector_output([(side(cache[f][LEFT]), side(cache[f][RIGHT])) for f in frame_ids], device)
 
 
 class Workspace:

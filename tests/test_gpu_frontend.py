@@ -351,3 +351,34 @@ def test_two_batches_in_flight_on_two_streams(device):
                 if n.startswith("inl_"):
                     a, b = a[:total], b[:total]
                 assert np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True), (mode, n)
+
+
+def test_frames_without_left_keypoints(device):
+    """A batch whose reference frames have no left keypoints at all: no slot per pair (cap = 0), eight
+    pairs -- every stage runs, nothing is written out of bounds, every count is zero."""
+    k, m1, m2 = read_cameras()
+    seq = SyntheticSequence(60, 9, seed=2)
+    frames = []
+    for f in seq.frames:
+        frames.append(type(f)(f.kpL[:0], f.kpR, f.descL[:0], f.descR, f.idL[:0], f.idR, f.Rt))
+    fe = pipeline.FrontEnd(k, m1, m2)
+    tb = pipeline.FrameTables.from_frames(frames, device)
+    H = 16
+    ws = fe.prepare(tb, n_hyp=H)
+    assert ws.cap == 0 and ws.P == 8 and ws.score_work.numel() >= 24 * ws.P
+    guard = ws.score_work.clone().fill_(7.0)
+    ws.score_work.copy_(guard)
+    Rt = torch.zeros((ws.P, H, 12), dtype=torch.float64, device=device)
+    fe.run(ws, Rt)
+    fe.run_ransac(ws, seed=1)
+    torch.cuda.synchronize()
+    assert torch.equal(ws.score_work, guard)                   # nothing to lay out, nothing touched
+    assert int(ws.cons.count.abs().sum()) == 0 and int(ws.counts.abs().sum()) == 0 and int(ws.n_inl.abs().sum()) == 0
+    assert int(ws.found.sum()) == 0
+    # only the later frame of every pair is empty: slots exist, still no consensus
+    mixed = [seq.frames[0]] + frames[1:3]
+    tb2 = pipeline.FrameTables.from_frames(mixed, device)
+    ws2 = fe.prepare(tb2, n_hyp=H)
+    fe.run(ws2, torch.zeros((ws2.P, H, 12), dtype=torch.float64, device=device))
+    torch.cuda.synchronize()
+    assert ws2.cap == 60 and int(ws2.cons.count.abs().sum()) == 0
