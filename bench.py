@@ -29,7 +29,6 @@ sys.path.insert(0, ROOT)
 
 INT_VALU_PEAK_TOPS = 78.6   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz simple int32 ops (nominal)
 INT_VALU_MEASURED_MIX_TOPS = 50.3  # tools/valu_peak.hip on the box: v_xor_b32 + v_bcnt_u32_b32 (bcnt is half rate)
-INT8_MFMA_PEAK_TOPS = 5000.0       # dense int8 MFMA = 2 x the 2.5 PFLOP/s bf16 peak
 FP4_MFMA_PEAK_TOPS = 10000.0       # dense fp4/fp6 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4) = 4 x bf16
 HBM_PEAK_GBS = 8000.0
 FP64_VALU_PEAK_TF = 78.6    # 256 CU x 64 fp64 FMA lanes/clk x 2 flop x 2.4 GHz
@@ -499,9 +498,9 @@ def main():
     # BASELINE's "INT roofline") and as multiply-accumulates on the matrix cores (8*D bit products per pair)
     valu_tops = 2.0 * words * match_pairs / (match_ms * 1e-3) / 1e12
     mfma_tops = 2.0 * 8 * tb.desc_bytes * match_pairs / (match_ms * 1e-3) / 1e12
-    knn_name = "hamming_knn_kernel" if valu_impl else ("hamming_fp4_kernel" if fp4_impl else "hamming_mfma_kernel")
-    mfma_peak = FP4_MFMA_PEAK_TOPS if fp4_impl else INT8_MFMA_PEAK_TOPS
-    mfma_unit = "TOP/s (fp4 matrix cores: one e2m1 slot per descriptor bit)" if fp4_impl else "TOP/s (int8)"
+    knn_name = "hamming_knn_kernel" if valu_impl else "hamming_fp4_kernel"
+    mfma_peak = FP4_MFMA_PEAK_TOPS
+    mfma_unit = "TOP/s (fp4 matrix cores: one e2m1 slot per descriptor bit)"
     match_roof = {
         "kernel": f"{knn_name} (2 launches per step: stereo k=1 + temporal k=2)",
         "bound": "valu" if valu_impl else "mfma",
@@ -576,7 +575,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": ("u32 popcount" if valu_impl else ("fp4 MFMA (exact Hamming)" if fp4_impl else "int8 MFMA (exact Hamming)")) + " matching + f64 triangulation + f32-filtered f64 scoring",
+        "dtype": ("u32 popcount" if valu_impl else "fp4 MFMA (exact Hamming)") + " matching + f64 triangulation + f32-filtered f64 scoring",
         "data": "synthetic",
         "config": {"workload": "configs[1]: consecutive frame pairs, 4-way match + PnP-RANSAC scoring of a fixed "
                                "seeded hypothesis set", "pairs_per_gpu_per_step": P, "keypoints_per_image": N,

@@ -40,6 +40,25 @@ int slam_version(void);
 const char *slam_last_error(void);
 
 /*
+ * Kernel variants with identical results, kept for cross-checks and A/B timing (no counterpart in
+ * the reference).  Process-wide; -1 leaves a choice as it is.  The defaults come from the
+ * environment variables SLAM_KNN_IMPL (fp4 | valu) and SLAM_SCORE_IMPL (auto | f64 | split | wide),
+ * read once when the library is loaded.
+ *   knn:   SLAM_KNN_FP4  Hamming distance on the fp4 matrix cores (default)
+ *          SLAM_KNN_VALU xor + popcount on the vector ALU
+ *   score: SLAM_SCORE_AUTO  fp32 first-level filter, form chosen from the launch size (default)
+ *          SLAM_SCORE_F64   fp64-only filter
+ *          SLAM_SCORE_SPLIT / SLAM_SCORE_WIDE  force one form of the fp32 first-level kernel
+ */
+#define SLAM_KNN_FP4 0
+#define SLAM_KNN_VALU 1
+#define SLAM_SCORE_AUTO 0
+#define SLAM_SCORE_F64 1
+#define SLAM_SCORE_SPLIT 2
+#define SLAM_SCORE_WIDE 3
+int slam_select_kernels(int knn, int score);
+
+/*
  * Repack binary descriptors [n, src_stride] (first desc_bytes bytes of each row
  * are the descriptor, e.g. 61 for AKAZE, 32 for ORB) into rows of dst_stride
  * bytes (32 or 64), zero padded.  This is the layout the matcher reads.
@@ -229,7 +248,7 @@ int slam_join_consensus(const int32_t *pair_dev, int n_pairs, int max_nq,
  * consensus sets it emits (point records and per-set bounds, for intrinsics K_host and the
  * scoring threshold thresh), so that the scoring call on these sets can be made with
  * work_ready = 1 (slam_score_hypotheses_range) and skips its own preparation pass.
- * score_work_dev: 24 * n_pairs * max(cap, 1) doubles, 16-byte aligned; NULL = plain join.
+ * score_work_dev: 16 * n_pairs * max(cap, 1) doubles, 16-byte aligned; NULL = plain join.
  */
 int slam_join_consensus_prepared(const int32_t *pair_dev, int n_pairs, int max_nq,
                                  const int32_t *t_idx_dev, const uint8_t *t_keep_dev,
@@ -258,7 +277,7 @@ int slam_join_consensus_prepared(const int32_t *pair_dev, int n_pairs, int max_n
  * A point supports iff both reprojection distances are < thresh (strict), all
  * in fp64 with one rounding per operation in the reference's order; no
  * cheirality test.
- * work_dev (nullable): caller-owned scratch of 24 * n_sets * max(cap, 1) doubles, 16-byte aligned.  When it
+ * work_dev (nullable): caller-owned scratch of 16 * n_sets * max(cap, 1) doubles, 16-byte aligned.  When it
  * is given, masks_dev is NULL and K is a pinhole matrix [fx 0 cx; 0 fy cy; 0 0 1],
  * evaluations are first run through a division-free filter and only the ones
  * within a guard band of the threshold are evaluated in the reference's order;
@@ -283,7 +302,7 @@ int slam_score_hypotheses(const double *Rt_dev, int n_sets, int H,
  * and no allocating library call.  Counts are identical to slam_score_hypotheses.
  *
  * Limit: n_sets * max(cap, 1) <= SLAM_SCORE_STATIC_MAX_POINTS point slots (the workspace is
- * SLAM_SCORE_WORK_PER_POINT doubles per slot = 12 MiB); larger batches are refused with
+ * SLAM_SCORE_WORK_PER_POINT doubles per slot = 8 MiB); larger batches are refused with
  * SLAM_ERR_UNSUPPORTED and must bring their own workspace.
  * All calls made with the same GPU current share that GPU's array, whatever their stream: two
  * such calls that overlap in time race on it.  Calls on one stream, or otherwise ordered, are
@@ -291,7 +310,7 @@ int slam_score_hypotheses(const double *Rt_dev, int n_sets, int H,
  * The first call on a device resolves the array's address (hipGetSymbolAddress); make that
  * first call outside any graph capture.
  */
-#define SLAM_SCORE_WORK_PER_POINT 24
+#define SLAM_SCORE_WORK_PER_POINT 16
 #define SLAM_SCORE_STATIC_MAX_POINTS 65536
 #define SLAM_SCORE_STATIC_WORK_DOUBLES (SLAM_SCORE_WORK_PER_POINT * SLAM_SCORE_STATIC_MAX_POINTS)
 int slam_score_hypotheses_static(const double *Rt_dev, int n_sets, int H,

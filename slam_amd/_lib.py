@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libslam_amd.so")
 EXPORTS = (
     "slam_version",
     "slam_last_error",
+    "slam_select_kernels",
     "slam_pack_descriptors",
     "slam_hamming_match",
     "slam_hamming_knn2",
@@ -67,6 +68,8 @@ def load():
     lib.slam_version.argtypes = []
     lib.slam_last_error.restype = ctypes.c_char_p
     lib.slam_last_error.argtypes = []
+    lib.slam_select_kernels.restype = ci
+    lib.slam_select_kernels.argtypes = [ci, ci]
     lib.slam_pack_descriptors.restype = ci
     lib.slam_pack_descriptors.argtypes = [vp, ci, ci, ci, vp, ci, vp]
     lib.slam_hamming_match.restype = ci
@@ -128,3 +131,14 @@ def check(status, what):
     if status != 0:
         msg = load().slam_last_error()
         raise SlamError(f"{what} failed ({status}): {msg.decode() if msg else ''}")
+
+
+KNN_VARIANTS = {"fp4": 0, "valu": 1}
+SCORE_VARIANTS = {"auto": 0, "mixed": 0, "f64": 1, "split": 2, "wide": 3}
+
+
+def select_kernels(knn=None, score=None):
+    """Process-wide choice of kernel variants with identical results (slam_select_kernels):
+    knn in KNN_VARIANTS, score in SCORE_VARIANTS; None leaves a choice alone."""
+    st = load().slam_select_kernels(-1 if knn is None else KNN_VARIANTS[knn], -1 if score is None else SCORE_VARIANTS[score])
+    check(st, "slam_select_kernels")

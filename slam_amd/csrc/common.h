@@ -31,4 +31,9 @@ inline int check_launch(const char *what)
 
 constexpr int WAVE = 64;
 
+// Kernel variants in force (slam_select_kernels; defaults from SLAM_KNN_IMPL / SLAM_SCORE_IMPL read once
+// when the library is loaded).
+int knn_impl();
+int score_impl();
+
 }  // namespace slam

@@ -279,14 +279,10 @@ extern "C" int slam_hamming_match(const uint8_t *q, const uint8_t *t, const int3
     a.out_dist = out_dist;
     a.keep = keep;
     hipStream_t s = (hipStream_t)stream;
-    // Three implementations with identical results: the fp4 matrix-core kernel (default), the
-    // int8 matrix-core kernel (SLAM_KNN_IMPL=mfma) and the VALU popcount kernel
-    // (SLAM_KNN_IMPL=valu), the latter two kept for comparison runs.
-    const char *impl = getenv("SLAM_KNN_IMPL");
-    if (!impl || impl[0] == 'f' || impl[0] == '\0')
+    // Two implementations with identical results: the fp4 matrix-core kernel (default) and the VALU
+    // popcount kernel (slam_select_kernels / SLAM_KNN_IMPL=valu), kept as the in-library cross-check.
+    if (knn_impl() != SLAM_KNN_VALU)
         return launch_knn_fp4(a, batch, max_nq, stride_bytes, s);
-    if (impl[0] != 'v')
-        return launch_knn_mfma(a, batch, max_nq, stride_bytes, s);
     if (stride_bytes == 64)
         return dispatch_q<16>(a, batch, max_nq, s);
     return dispatch_q<8>(a, batch, max_nq, s);

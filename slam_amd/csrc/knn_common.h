@@ -1,4 +1,4 @@
-// Shared pieces of the two Hamming k-NN kernels (VALU popcount and int8 MFMA).
+// Shared pieces of the Hamming k-NN kernels (VALU popcount and fp4 matrix cores).
 #pragma once
 #include "common.h"
 
@@ -78,8 +78,6 @@ __device__ __forceinline__ void knn_store(const KnnArgs &a, int qs, int ts, int 
     }
 }
 
-// Launches the int8-MFMA kernel (knn_mfma.hip).
-int launch_knn_mfma(const KnnArgs &a, int batch, int max_nq, int stride_bytes, hipStream_t s);
 // Launches the fp4-MFMA kernel (knn_fp4.hip).
 int launch_knn_fp4(const KnnArgs &a, int batch, int max_nq, int stride_bytes, hipStream_t s);
 

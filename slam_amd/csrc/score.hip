@@ -134,27 +134,13 @@ constexpr int SCORE_QUEUE = 16;  // undecided points a lane can park before it f
 
 __device__ __forceinline__ double *score_recs64(const ScoreArgs &a) { return score_work_recs64(a.work); }
 __device__ __forceinline__ float *score_recs32(const ScoreArgs &a) { return score_work_recs32(a.work, a.n_rec); }
-__device__ __forceinline__ uint4 *score_recs16(const ScoreArgs &a) { return score_work_recs16(a.work, a.n_rec); }
 __device__ __forceinline__ double *score_hdr(const ScoreArgs &a) { return score_work_hdr(a.work, a.n_rec); }
-
-// v = p0 + p1 + p2 exactly, each piece a bf16 (8 significant bits, same sign as v): the bf16 bit
-// patterns.  (Pieces below the fp32 denormal range are lost: an absolute error under 2^-126.)
-__device__ __forceinline__ void split3(float v, uint32_t &p0, uint32_t &p1, uint32_t &p2)
-{
-    const uint32_t b0 = __float_as_uint(v) & 0xFFFF0000u;
-    const float r1 = v - __uint_as_float(b0);
-    const uint32_t b1 = __float_as_uint(r1) & 0xFFFF0000u;
-    const float r2 = r1 - __uint_as_float(b1);
-    p0 = b0 >> 16;
-    p1 = b1 >> 16;
-    p2 = __float_as_uint(r2) >> 16;
-}
 
 // Widens the point data to fp64 records, writes the fp32 records and reduces the per-set
 // magnitude bounds (non-negative doubles order like their bit patterns, so an integer atomic
 // max does it).  A NaN magnitude maps to the largest pattern and ends up disabling the
 // filters for the set.
-__global__ void __launch_bounds__(256) score_prep_kernel(const ScoreArgs a, int chunks_per_set, bool want_bf16)
+__global__ void __launch_bounds__(256) score_prep_kernel(const ScoreArgs a, int chunks_per_set)
 {
     __shared__ unsigned long long red[3][4];
     const int set = blockIdx.x / chunks_per_set;
@@ -170,27 +156,6 @@ __global__ void __launch_bounds__(256) score_prep_kernel(const ScoreArgs a, int 
         const double X = a.X[o], Y = a.Y[o], Z = a.Z[o];
         score_write_record(a.work, a.n_rec, o, X, Y, Z, a.uL[o], a.vL[o], a.uR[o], a.vR[o], a.K.m[0], a.K.m[4], a.K.m[2],
                            a.K.m[5], a.thresh, am, um, wm);
-        // k-slot layout of the matrix-core kernel: slots 9t + 3i + j (t = X, Y, Z) pair piece i
-        // of a coefficient with piece j of the coordinate; slots 27..29 pair the constant term's
-        // pieces with 1.0; slots 30, 31 are unused
-        if (want_bf16) {
-            const float c3[3] = {(float)X, (float)Y, (float)Z};
-            uint32_t pc[3][3];
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-                split3(c3[t], pc[t][0], pc[t][1], pc[t][2]);
-            uint32_t slot[32];
-#pragma unroll
-            for (int k = 0; k < 27; ++k)
-                slot[k] = pc[k / 9][k % 3];
-            slot[27] = slot[28] = slot[29] = 0x3F80u;   // 1.0
-            slot[30] = slot[31] = 0u;
-            uint4 *r16 = score_recs16(a) + 4 * o;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                r16[c] = make_uint4(slot[8 * c] | (slot[8 * c + 1] << 16), slot[8 * c + 2] | (slot[8 * c + 3] << 16),
-                                    slot[8 * c + 4] | (slot[8 * c + 5] << 16), slot[8 * c + 6] | (slot[8 * c + 7] << 16));
-        }
     }
     am = wave_max_u64(am);
     um = wave_max_u64(um);
@@ -610,322 +575,6 @@ __global__ void __launch_bounds__(256) score_mixed_kernel(const ScoreArgs a)
     }
 }
 
-// ---- matrix-core variant -----------------------------------------------------------------
-// The three affine maps of an evaluation (hz, gx, gy, and gx + the right camera's offset) are
-// 4-term dot products of a hypothesis row with (X, Y, Z, 1).  With every fp32 factor split
-// exactly into three bf16 pieces, a*b is the sum of the nine piece products, each exact in
-// fp32, so one output is a 30-term bf16 dot product: two v_mfma_f32_32x32x16_bf16 per output
-// for a tile of 32 hypotheses x 32 points.  That moves 10 of the 26 VALU instructions of an
-// evaluation to the matrix cores; the rest of the fp32 filter (16 instructions per evaluation)
-// runs on the VALU over the accumulator tile, lane = point, register = hypothesis.
-//
-// Error budget.  The products are exact; what remains is the fp32 accumulation inside the MFMA:
-// at most 32 additions per output in an order the hardware chooses, each off by at most 2u
-// relative (u = 2^-24; covers round-to-nearest and truncation), plus the rounding of the inputs
-// to fp32.  So |o^ - o| <= 66u * M with M the sum of the magnitudes of the four terms, in place
-// of the 5u of the fma chain, and the guard band of score_mixed_kernel is reused with
-// Wb = 94.8*Wmax + 67 and the bounds c1, ca, cb taken over the 32 hypotheses of the wavefront.
-// About 2 in 1000 evaluations are undecided; they are parked per lane and settled by
-// supports() after the loop, exactly as in score_mixed_kernel.
-using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
-using f32x16 = float __attribute__((ext_vector_type(16)));
-
-constexpr int SM_STAGE = 128;     // points per LDS stage (4 tiles of 32)
-constexpr int SM_STAGE_BYTES = SM_STAGE * 96;   // per point 64 bytes of bf16 operands + 32 of fp32 record
-constexpr int SM_QUEUE = 1024;    // undecided evaluations a wavefront can park before it recounts in fp64
-
-// bf16 bits of k-slot k of a hypothesis row with coefficient pieces pc[t][i] (t = X, Y, Z, 1)
-__device__ __forceinline__ uint32_t coef_slot(const uint32_t (&pc)[4][3], int k)
-{
-    if (k < 27)
-        return pc[k / 9][(k % 9) / 3];
-    if (k < 30)
-        return pc[3][k - 27];
-    return 0u;
-}
-
-__global__ void __launch_bounds__(256) score_mfma_kernel(const ScoreArgs a)
-{
-    // two separate arrays, each named statically where it is used: the compiler then knows that a
-    // read of one does not have to wait for the copy in flight into the other
-    __shared__ __attribute__((aligned(16))) uint8_t stage0[SM_STAGE_BYTES];
-    __shared__ __attribute__((aligned(16))) uint8_t stage1[SM_STAGE_BYTES];
-    __shared__ unsigned queue[4][SM_QUEUE];     // per wavefront: (hypothesis row << 24) | point
-    __shared__ int tally[4][32];
-
-    const int set = blockIdx.x / a.blocks_per_set;
-    const int blk = blockIdx.x - set * a.blocks_per_set;
-    if (a.skip && a.skip[set])
-        return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int col = lane & 31, half = lane >> 5;
-    const int h_base = blk * 128 + wave * 32;
-    const int h = h_base + col;                 // this lane's hypothesis row (both halves hold it)
-    const bool live = h < a.H;
-    const double *hdr = score_hdr(a) + SCORE_HDR * set;
-    const double Amax = hdr[0], Umax = hdr[1], Wmax = hdr[2];
-    int n = a.n_dev ? a.n_dev[set] : a.n_host;
-    n = min(max(n, 0), a.cap);
-    n = __builtin_amdgcn_readfirstlane(n);
-    if (tid < 128)
-        tally[tid >> 5][tid & 31] = 0;
-
-    // ---- hypothesis rows -> A operands ------------------------------------------------------
-    const double fx = a.K.m[0], fy = a.K.m[4], cx = a.K.m[2], cy = a.K.m[5], thr = a.thresh;
-    uint4 Aop[4][2];
-    bool dead, row_ok;
-    double Brot = 0.0, T = 0.0;
-    {
-        double rt[12];
-        const double *pose = a.Rt + ((size_t)set * a.Hs + (live ? h : 0)) * 12;
-#pragma unroll
-        for (int c = 0; c < 12; c += 2) {
-            const double2 v = *reinterpret_cast<const double2 *>(pose + c);
-            rt[c] = v.x;
-            rt[c + 1] = v.y;
-        }
-        dead = !live;
-#pragma unroll
-        for (int c = 0; c < 12; ++c)
-            dead = dead || !(fabs(rt[c]) < __builtin_inf());
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                Brot = fmax(Brot, fabs(rt[4 * r + c]));
-        T = fmax(fmax(fabs(rt[3]), fabs(rt[7])), fabs(rt[11])) + a.trmax;
-        // The magnitude limits (here and on Amax below) keep every fp32 intermediate finite, so
-        // that the sign tests of the tile loop never see a NaN: |hz| < 2e12, |g|, |u*hz| < 6e17,
-        // squared residuals < 2e36.
-        row_ok = dead || ((Brot > 1e-30) && (Brot < 1e6) && (T < 1e9));
-        if (dead)
-            Brot = T = 0.0;
-        const double sfx = fx / thr, sfy = fy / thr;
-        // outputs: 0 = hz, 1 = gx, 2 = gy, 3 = gx + right-camera offset
-        float co[4][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            co[0][c] = (float)rt[8 + c];
-            co[1][c] = (float)(sfx * rt[c]);
-            co[2][c] = (float)(sfy * rt[4 + c]);
-            co[3][c] = co[1][c];
-        }
-        co[3][3] = (float)(sfx * rt[3] + sfx * a.tr.v[0]);
-        if (dead) {
-            // a row that supports nothing: depth 0 and a projection 2^60 thresholds away is "sure out"
-#pragma unroll
-            for (int o = 0; o < 4; ++o)
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    co[o][c] = 0.0f;
-            co[1][3] = co[3][3] = 1.152921504606846976e18f;
-        }
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            uint32_t pc[4][3];
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                split3(co[o][c], pc[c][0], pc[c][1], pc[c][2]);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                uint32_t w[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t lo0 = coef_slot(pc, 16 * m + 2 * e), hi0 = coef_slot(pc, 16 * m + 2 * e + 1);
-                    const uint32_t lo1 = coef_slot(pc, 16 * m + 8 + 2 * e), hi1 = coef_slot(pc, 16 * m + 8 + 2 * e + 1);
-                    w[e] = half ? (lo1 | (hi1 << 16)) : (lo0 | (hi0 << 16));
-                }
-                Aop[o][m] = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-        }
-    }
-    // bounds over the 32 rows of the wavefront
-    double Bw = Brot, Tw = T;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        Bw = fmax(Bw, __shfl_xor(Bw, off));
-        Tw = fmax(Tw, __shfl_xor(Tw, off));
-    }
-    const double u24 = 5.9604644775390625e-08;
-    const double Wb = 94.8 * Wmax + 67.0;
-    const double tau = 2.0 * u24 * Wb * Bw;
-    const double c1d = (0.5 * tau + 4.03 * u24) * 1.001;
-    const double cad = (2.0 * u24 * u24 * Wb * Wb * Bw * Bw / tau) * 1.001;
-    const double cbd = (2.0 * u24 * u24 * Wb * Wb * Tw * Tw / tau) * 1.001 + 1e-30;
-    const double mag = fabs(fx) + fabs(fy) + fabs(cx) + fabs(cy) + Umax + fabs(thr);
-    const bool set_ok = (thr > 0.0) && (mag / thr < 262144.0) && (Wmax >= 0.015625) && (Wmax < 262144.0) &&
-                        (fabs(cx) <= 64.0 * thr * Wmax) && (fabs(cy) <= 64.0 * thr * Wmax) && (Amax < 1e6) &&
-                        (tau < 0.125) && (cbd < 1e30) && (cad < 1e30);
-    const bool any_live = __ballot(!dead) != 0ull;
-    // the whole wavefront takes the fp64 route when the fp32 stage cannot be trusted for it
-    bool wave_exact = any_live && (!set_ok || __ballot(!row_ok) != 0ull || !(cad > 1e-30));
-    const float c1 = (float)c1d, caw = (float)cad, cbw = (float)cbd;
-
-    const uint8_t *g16 = reinterpret_cast<const uint8_t *>(score_recs16(a) + 4 * ((size_t)set * a.cap));
-    const uint8_t *g32 = reinterpret_cast<const uint8_t *>(score_recs32(a) + (size_t)SCORE_REC32 * ((size_t)set * a.cap));
-    // A stage is copied global -> LDS by the DMA path (no registers): one wave-instruction fills
-    // 64 consecutive 16-byte chunks of LDS from 64 per-lane global addresses.  LDS image of a
-    // stage: chunk (part, p) at (part * 128 + p) * 16 -- parts 0..3 the bf16 operand record of
-    // point p, parts 4, 5 its fp32 record -- so that every tile read is 32 consecutive chunks.
-    // Points past n re-read point n - 1; their results are masked or never computed.
-    auto load_stage = [&](int s, uint8_t *to) __attribute__((always_inline)) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int idx = tid + 256 * c;          // 768 = 6 parts x 128 points
-            const int part = idx >> 7, pt = idx & 127;
-            const int gp = min(s * SM_STAGE + pt, n - 1);
-            const uint8_t *src = part < 4 ? g16 + (size_t)gp * 64 + 16 * part : g32 + (size_t)gp * 32 + 16 * (part - 4);
-            uint8_t *dst = to + (64 * wave + 256 * c) * 16;   // wave-uniform: the hardware adds lane * 16
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-        }
-    };
-
-    unsigned bits[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-        bits[r] = 0u;
-    int wqn = 0;                    // wave-uniform: entries parked so far (may run past SM_QUEUE)
-    const f32x16 zero = {};
-    auto row_of = [&](int r) __attribute__((always_inline)) { return (r & 3) + 8 * (r >> 2) + 4 * half; };
-    auto flush = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int c = __popc(bits[r]);
-            if (c)
-                atomicAdd(&tally[wave][row_of(r)], c);
-            bits[r] = 0u;
-        }
-    };
-
-    const int n_stages = (n + SM_STAGE - 1) / SM_STAGE;
-    const bool run32 = any_live && !wave_exact;     // wave-uniform
-    if (n_stages > 0)
-        load_stage(0, stage0);
-    __syncthreads();
-    // one stage: start the copy of the next one into `nxt`, work through the tiles of `cur`
-    auto do_stage = [&](int s, uint8_t *cur, uint8_t *nxt) __attribute__((always_inline)) {
-        if (s + 1 < n_stages)
-            load_stage(s + 1, nxt);
-        if (run32) {
-            // one tile of 32 points x the wavefront's 32 hypotheses; RAGGED: the tile may run past n
-            auto do_tile = [&](int tile, auto ragged_tag) __attribute__((always_inline)) {
-                constexpr bool RAGGED = decltype(ragged_tag)::value;
-                const int gp = s * SM_STAGE + 32 * tile + col;
-                const uint8_t *pt = cur + (32 * tile + col) * 16;       // chunk of part 0
-                const uint4 b0 = *reinterpret_cast<const uint4 *>(pt + (0 + half) * 2048);
-                const uint4 b1 = *reinterpret_cast<const uint4 *>(pt + (2 + half) * 2048);
-                const float ul = *reinterpret_cast<const float *>(pt + 4 * 2048 + 12);
-                const float4 f = *reinterpret_cast<const float4 *>(pt + 5 * 2048);   // vl ur vr A2
-                f32x16 acc[4];
-#pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Aop[o][0]),
-                                                                     __builtin_bit_cast(bf16x8, b0), zero, 0, 0, 0);
-                    acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Aop[o][1]),
-                                                                     __builtin_bit_cast(bf16x8, b1), acc[o], 0, 0, 0);
-                }
-                const float rb = __builtin_fmaf(caw, f.w, cbw);
-                // d = m - w (sign = verdict) and the bound its magnitude has to exceed to be sure
-                auto elem = [&](int r, float &d, float &rr) __attribute__((always_inline)) {
-                    const float hz = acc[0][r], gx = acc[1][r], gy = acc[2][r], gxr = acc[3][r];
-                    const float dxl = __builtin_fmaf(ul, hz, -gx);
-                    const float dyl = __builtin_fmaf(f.x, hz, -gy);
-                    const float dxr = __builtin_fmaf(f.y, hz, -gxr);
-                    const float dyr = __builtin_fmaf(f.z, hz, -gy);
-                    const float sl = __builtin_fmaf(dxl, dxl, dyl * dyl);
-                    const float sr = __builtin_fmaf(dxr, dxr, dyr * dyr);
-                    const float m = fmaxf(sl, sr);
-                    const float w = hz * hz;
-                    d = m - w;
-                    rr = __builtin_fmaf(c1, m + w, rb);
-                };
-                const bool valid = !RAGGED || gp < n;
-                unsigned sure = 0u;             // bit 15 - r: element r of this lane is decided
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float d, rr;
-                    elem(r, d, rr);
-                    // d + rr < 0: surely a supporter; rr - |d| < 0: decided.  Both signs are exact
-                    // (a sum of two finite floats rounds to zero only when it is zero).
-                    float in = d + rr, dec = rr - fabsf(d);
-                    if (RAGGED) {               // points past the end: a 0 bit, never undecided
-                        in = valid ? in : 1.0f;
-                        dec = valid ? dec : -1.0f;
-                    }
-                    bits[r] = __builtin_amdgcn_alignbit(bits[r], __float_as_uint(in), 31);
-                    sure = __builtin_amdgcn_alignbit(sure, __float_as_uint(dec), 31);
-                }
-                // park the undecided elements (about two per tile), packed per wavefront
-                unsigned und = ~sure & 0xFFFFu;
-                unsigned long long mk;
-                while ((mk = __ballot(und != 0u)) != 0ull) {
-                    if (und != 0u) {
-                        const int b = __ffs(und) - 1;
-                        und &= und - 1u;
-                        const int pos = wqn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32),
-                                                   __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                        if (pos < SM_QUEUE)
-                            queue[wave][pos] = ((unsigned)row_of(15 - b) << 24) | (unsigned)gp;
-                    }
-                    wqn += __popcll(mk);
-                }
-            };
-            const int left = n - s * SM_STAGE;         // points in this stage (> 0)
-            const int full_tiles = min(left, SM_STAGE) / 32;
-#pragma unroll 1
-            for (int tile = 0; tile < full_tiles; ++tile)
-                do_tile(tile, std::false_type{});
-            if (full_tiles < SM_STAGE / 32 && left > 32 * full_tiles)
-                do_tile(full_tiles, std::true_type{});
-            if ((s & 7) == 7)
-                flush();
-        }
-        __syncthreads();
-    };
-    for (int s = 0; s < n_stages; s += 2) {
-        do_stage(s, stage0, stage1);
-        if (s + 1 < n_stages)
-            do_stage(s + 1, stage1, stage0);
-    }
-    if (run32)
-        flush();
-
-    // ---- settle the undecided evaluations in fp64 -------------------------------------------
-    const double *__restrict__ recs64 = score_recs64(a) + (size_t)SCORE_REC * ((size_t)set * a.cap);
-    auto exact = [&](int hyp, int gp) __attribute__((always_inline)) -> bool {
-        double rt[12];
-        const double *pose = a.Rt + ((size_t)set * a.Hs + hyp) * 12;
-#pragma unroll
-        for (int c = 0; c < 12; ++c)
-            rt[c] = pose[c];
-        const double *r = recs64 + (size_t)SCORE_REC * gp;
-        return supports(rt, a.K, a.tr, r[0], r[1], r[2], r[3], r[4], r[5], r[6], a.thresh);
-    };
-    if (wqn > SM_QUEUE)
-        wave_exact = any_live;            // the queue overflowed: recount the wavefront's rows
-    if (!wave_exact) {
-        for (int q = lane; q < wqn; q += 64) {
-            const unsigned e = queue[wave][q];
-            const int row = (int)(e >> 24), gp = (int)(e & 0xFFFFFFu);
-            if (h_base + row < a.H && exact(h_base + row, gp))
-                atomicAdd(&tally[wave][row], 1);
-        }
-    }
-    __syncthreads();
-    if (half == 0 && live) {
-        int cnt = tally[wave][col];
-        if (wave_exact) {
-            cnt = 0;
-            if (!dead)
-                for (int i = 0; i < n; ++i)
-                    cnt += exact(h, i) ? 1 : 0;
-        }
-        a.counts[(size_t)set * a.Hs + h] = dead ? 0 : cnt;
-    }
-}
-
 }  // namespace
 }  // namespace slam
 
@@ -1009,12 +658,10 @@ extern "C" int slam_score_hypotheses_range(const double *Rt, int n_sets, int H_t
         pinhole = pinhole && (t_right[i] - t_right[i] == 0.0);
     if (work && !masks && pinhole && cap > 0) {
         a.n_rec = (size_t)n_sets * cap;
-        // SLAM_SCORE_IMPL=f64 keeps the fp64-only filter kernel for rectified stereo (A/B timing),
-        // SLAM_SCORE_IMPL=bf16 the matrix-core variant; the counts are identical either way.
-        const char *impl = getenv("SLAM_SCORE_IMPL");
-        const bool f64_only = impl && impl[0] == 'f' && impl[1] == '6';
-        const bool use_mfma = impl && impl[0] == 'b';
-        if (!work_ready || use_mfma) {   // (the matrix-core variant has operand records only this pass writes)
+        // slam_select_kernels / SLAM_SCORE_IMPL pick the fp64-only filter kernel or force one form of the
+        // fp32-first-level kernel (A/B timing, tests); the counts are identical either way.
+        const int impl = score_impl();
+        if (!work_ready) {
             hipError_t e =
                 hipMemsetAsync(work + SCORE_WORK_PER_REC * a.n_rec, 0, sizeof(double) * SCORE_HDR * (size_t)n_sets, s);
             if (e != hipSuccess)
@@ -1022,24 +669,17 @@ extern "C" int slam_score_hypotheses_range(const double *Rt, int n_sets, int H_t
             const int chunks = (cap + 255) / 256;
             if ((long long)n_sets * chunks > 0x7FFFFFFFLL)
                 return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: grid too large");
-            hipLaunchKernelGGL(score_prep_kernel, dim3((unsigned)(n_sets * chunks)), dim3(256), 0, s, a, chunks, use_mfma);
+            hipLaunchKernelGGL(score_prep_kernel, dim3((unsigned)(n_sets * chunks)), dim3(256), 0, s, a, chunks);
         }
         a.blocks_per_set = (H + 255) / 256;
         const long long blocks = (long long)n_sets * a.blocks_per_set;
         if (blocks > 0x7FFFFFFFLL)
             return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: grid too large");
         if (t_right[1] == 0.0 && t_right[2] == 0.0) {
-            if (f64_only) {
+            if (impl == SLAM_SCORE_F64) {
                 hipLaunchKernelGGL(score_fast_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
-            } else if (use_mfma) {
-                a.blocks_per_set = (H + 127) / 128;
-                const long long mblocks = (long long)n_sets * a.blocks_per_set;
-                if (mblocks > 0x7FFFFFFFLL)
-                    return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: grid too large");
-                hipLaunchKernelGGL(score_mfma_kernel, dim3((unsigned)mblocks), dim3(256), 0, s, a);
-            } else if ((impl && impl[0] == 's') || (!(impl && impl[0] == 'w') && (long long)n_sets * ((H + 63) / 64) < 3072)) {
+            } else if (impl == SLAM_SCORE_SPLIT || (impl != SLAM_SCORE_WIDE && (long long)n_sets * ((H + 63) / 64) < 3072)) {
                 // fewer than three wavefronts per SIMD: split the points of a set over a block
-                // (SLAM_SCORE_IMPL=split / wide force one form or the other, for tests and timing)
                 a.blocks_per_set = (H + 63) / 64;
                 hipLaunchKernelGGL(score_mixed_kernel<true>, dim3((unsigned)(n_sets * a.blocks_per_set)), dim3(256), 0, s,
                                    a);

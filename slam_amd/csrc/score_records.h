@@ -8,7 +8,6 @@
 //   [n_rec][4]            fp32 point records (8 floats, threshold units, principal point removed)
 //                            X Y Z (uL-cx)/thr (vL-cy)/thr (uR-cx)/thr (vR-cy)/thr A2
 //                         A2 >= (|X|+|Y|+|Z|)^2, rounded up
-//   [n_rec][8]            bf16 operand records of the matrix-core kernel (32 bf16 = 64 bytes)
 //   [n_sets][4]           per-set bounds kept as the bit patterns of non-negative doubles:
 //                         Amax = max(|X|+|Y|+|Z|), Umax = max(|uL|+|vL|+|uR|+|vR|),
 //                         Wmax = max(|u-cx|+|fx|, |v-cy|+|fy|)/thr over both cameras, pad
@@ -20,16 +19,12 @@ namespace slam {
 constexpr int SCORE_REC = 8;
 constexpr int SCORE_REC32 = 8;   // floats
 constexpr int SCORE_HDR = 4;
-constexpr int SCORE_WORK_PER_REC = SCORE_REC + 4 + 8;   // doubles of workspace per point record
+constexpr int SCORE_WORK_PER_REC = SCORE_REC + 4;   // doubles of workspace per point record
 
 __device__ __forceinline__ double *score_work_recs64(double *work) { return work; }
 __device__ __forceinline__ float *score_work_recs32(double *work, size_t n_rec)
 {
     return reinterpret_cast<float *>(work + SCORE_REC * n_rec);
-}
-__device__ __forceinline__ uint4 *score_work_recs16(double *work, size_t n_rec)
-{
-    return reinterpret_cast<uint4 *>(work + (SCORE_REC + 4) * n_rec);
 }
 __device__ __forceinline__ double *score_work_hdr(double *work, size_t n_rec)
 {

@@ -311,7 +311,7 @@ def score_hypotheses(Rt, K, t_right, X, Y, Z, uL, vL, uR, vR, thresh=2.0, cap=No
     Rt: [n_sets, H, 3, 4] (or [H,3,4] for one set) f64.  Points: flat SoA with set s
     at [s*cap, s*cap+n_s).  Returns counts [n_sets,H] i32 (and masks [n_sets,H,words] as
     int64 bit patterns when want_masks).  `fast` lets the library use its filtered path
-    (needs a scratch tensor `work` of 24*n_sets*cap doubles, allocated here if absent);
+    (needs a scratch tensor `work` of 16*n_sets*cap doubles, allocated here if absent);
     counts are identical with fast=False.
     """
     lib = _lib.load()
@@ -330,7 +330,7 @@ def score_hypotheses(Rt, K, t_right, X, Y, Z, uL, vL, uR, vR, thresh=2.0, cap=No
     masks = torch.zeros((n_sets, H, max(words, 1)), dtype=torch.int64, device=dev) if want_masks else None
     null = ctypes.c_void_p(0)
     if fast and not want_masks and work is None:
-        work = torch.empty(24 * max(n_sets * cap, 1), dtype=torch.float64, device=dev)
+        work = torch.empty(16 * max(n_sets, 1) * max(cap, 1), dtype=torch.float64, device=dev)
     st = lib.slam_score_hypotheses(
         _dev(Rt, torch.float64, "Rt"), n_sets, H, pK, pt, _dev(X, torch.float64, "X"), _dev(Y, torch.float64, "Y"),
         _dev(Z, torch.float64, "Z"), _dev(uL, torch.float32, "uL"), _dev(vL, torch.float32, "vL"),

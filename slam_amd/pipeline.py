@@ -205,7 +205,7 @@ class FrontEnd:
         ws.mask_words = (ws.cap + 63) // 64
         ws.masks = (torch.zeros((max(ws.P, 1), max(ws.H, 1), max(ws.mask_words, 1)), dtype=torch.int64, device=dev)
                     if want_masks else None)
-        ws.score_work = f64(24 * max(ws.P, 1) * max(ws.cap, 1))    # the size include/slam_amd.h asks for
+        ws.score_work = f64(16 * max(ws.P, 1) * max(ws.cap, 1))    # the size include/slam_amd.h asks for
         ws.work_ready = 0          # 1 once the join has laid out score_work for the current consensus sets
         # winner selection + inlier tables
         np_ = max(ws.P, 1)

@@ -52,10 +52,10 @@ def _mask_bits(mask_words, n):
     return np.unpackbits(mask_words.view(np.uint8), bitorder="little")[:n].astype(bool)
 
 
-def test_headline_workload_counts_winners_and_tables(device, monkeypatch):
+def test_headline_workload_counts_winners_and_tables(device):
     """BASELINE configs[1] as bench.py runs it: 2000 keypoints, H = 10 000, default kernels."""
-    for var in ("SLAM_SCORE_IMPL", "SLAM_KNN_IMPL"):
-        monkeypatch.delenv(var, raising=False)
+    from slam_amd import _lib
+    _lib.select_kernels("fp4", "auto")
     k, m1, m2 = read_cameras()
     Pm, Qm = k @ m1, k @ m2
     n_pairs, H = 24, 10000          # 24 x ceil(10000/64) blocks: past the point where the wide kernel form is chosen

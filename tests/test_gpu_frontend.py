@@ -365,7 +365,7 @@ def test_frames_without_left_keypoints(device):
     tb = pipeline.FrameTables.from_frames(frames, device)
     H = 16
     ws = fe.prepare(tb, n_hyp=H)
-    assert ws.cap == 0 and ws.P == 8 and ws.score_work.numel() >= 24 * ws.P
+    assert ws.cap == 0 and ws.P == 8 and ws.score_work.numel() >= 16 * ws.P
     guard = ws.score_work.clone().fill_(7.0)
     ws.score_work.copy_(guard)
     Rt = torch.zeros((ws.P, H, 12), dtype=torch.float64, device=device)

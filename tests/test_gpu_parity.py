@@ -23,17 +23,16 @@ def _rand_desc(rng, n, D):
 
 
 # --------------------------------------------------------------------------- knn
-@pytest.fixture(params=["fp4", "valu", "bf16", "wide"], autouse=True)
-def kernel_impl(request, monkeypatch):
-    """Every test in this file runs against the implementations of the k-NN kernel (fp4 matrix
-    cores, VALU popcount, int8 matrix cores) and of the filtered scoring kernel (fp32 first level
-    on the VALU with the points of a set split over a block or not, fp64 only, fp32 first level
-    with the projections on the bf16 matrix cores); the selectors are read on every call."""
-    knn, score = {"fp4": ("fp4", "split"), "valu": ("valu", "f64"), "bf16": ("mfma", "bf16"),
-                  "wide": ("fp4", "wide")}[request.param]
-    monkeypatch.setenv("SLAM_KNN_IMPL", knn)
-    monkeypatch.setenv("SLAM_SCORE_IMPL", score)
-    return request.param
+@pytest.fixture(params=["fp4", "valu", "wide"], autouse=True)
+def kernel_impl(request):
+    """Every test in this file runs against both implementations of the k-NN kernel (fp4 matrix
+    cores, VALU popcount) and the forms of the filtered scoring kernel (fp32 first level with the
+    points of a set split over a block or not, fp64 only)."""
+    from slam_amd import _lib
+    knn, score = {"fp4": ("fp4", "split"), "valu": ("valu", "f64"), "wide": ("fp4", "wide")}[request.param]
+    _lib.select_kernels(knn, score)
+    yield request.param
+    _lib.select_kernels("fp4", "auto")
 
 
 @pytest.mark.parametrize("D,stride", [(61, 64), (64, 64), (32, 32), (32, 64), (17, 32)])

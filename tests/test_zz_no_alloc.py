@@ -62,7 +62,7 @@ def _run(lib, dev, case, cap, static):
         st = lib.slam_score_hypotheses_static(p(dRt), n_sets, H, K9, t3, *[p(x) for x in d], cap, p(dn), 0, 2.0,
                                               p(counts), stream)
     else:
-        work = torch.empty(24 * n_sets * max(cap, 1), dtype=torch.float64, device=dev)
+        work = torch.empty(16 * n_sets * max(cap, 1), dtype=torch.float64, device=dev)
         st = lib.slam_score_hypotheses(p(dRt), n_sets, H, K9, t3, *[p(x) for x in d], cap, p(dn), 0, 2.0, p(counts),
                                        None, 0, p(work), stream)
     _lib.check(st, "score")

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from slam_amd import pipeline                                                     # noqa: E402
+from slam_amd import _lib, pipeline                                                     # noqa: E402
 from slam_amd.synthetic import SyntheticSequence, read_cameras, seeded_hypotheses  # noqa: E402
 
 P, N, H = int(os.environ.get("AB_PAIRS", "128")), 2000, int(os.environ.get("AB_HYP", "10000"))
@@ -36,12 +36,12 @@ def timed(fn, reps=3):
     return e0.elapsed_time(e1) / reps
 
 
-res = {"score": {"mixed": [], "f64": [], "bf16": []}, "knn": {"mfma": [], "valu": [], "fp4": []}}
+res = {"score": {"mixed": [], "f64": []}, "knn": {"valu": [], "fp4": []}}
 for rnd in range(8):
-    for impl, simpl in (("mfma", "mixed"), ("valu", "f64"), ("fp4", "bf16")):
-        os.environ["SLAM_SCORE_IMPL"] = simpl
+    for impl, simpl in (("fp4", "mixed"), ("valu", "f64")):
+        _lib.select_kernels(score=simpl)
         res["score"][simpl].append(timed(lambda: fe.score(ws, Rt, stream)))
-        os.environ["SLAM_KNN_IMPL"] = impl
+        _lib.select_kernels(knn=impl)
         res["knn"][impl].append(timed(lambda: (fe.stereo_match(ws, stream), fe.temporal_match(ws, stream))))
 for kname, d in res.items():
     for impl, v in d.items():

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from slam_amd import ops                                                   # noqa: E402
+from slam_amd import _lib, ops                                                   # noqa: E402
 
 dev = torch.device("cuda:0")
 EDGE = [0, 1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 2047, 2048, 2049, 3000]
@@ -42,8 +42,8 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     qd = ops.pack_descriptors(torch.from_numpy(q).to(dev), D, stride) if q.shape[0] else torch.zeros((0, stride), dtype=torch.uint8, device=dev)
     td = ops.pack_descriptors(torch.from_numpy(t).to(dev), D, stride) if t.shape[0] else torch.zeros((0, stride), dtype=torch.uint8, device=dev)
     out = {}
-    for impl in ("mfma", "valu", "fp4"):
-        os.environ["SLAM_KNN_IMPL"] = impl
+    for impl in ("valu", "fp4"):
+        _lib.select_kernels(knn=impl)
         idx, dist, keep = ops.hamming_match(qd, td, torch.from_numpy(seg).to(dev), max(nq), max(nt), D, k=2, mode=mode,
                                             thr=thr, yq=yq if mode == 2 else None, yt=yt if mode == 2 else None,
                                             n_rows=int(q.shape[0]))
@@ -51,7 +51,7 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
         out[impl] = (idx.cpu().numpy(), dist.cpu().numpy(), None if keep is None else keep.cpu().numpy())
     b = out["valu"]
     d = 0
-    for a in (out["mfma"], out["fp4"]):
+    for a in (out["fp4"],):
         d += int((a[0] != b[0]).sum() + (a[1] != b[1]).sum() + (0 if a[2] is None else (a[2] != b[2]).sum()))
     pairs += int(sum(x * y for x, y in zip(nq, nt)))
     if d:

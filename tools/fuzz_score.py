@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from slam_amd import ops                                                   # noqa: E402
+from slam_amd import _lib, ops                                                   # noqa: E402
 from slam_amd.synthetic import read_cameras, seeded_hypotheses             # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -46,8 +46,8 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 24):
     Rt = pose + (Rt - pose) * 10.0 ** rng.uniform(-6, -1, (H, 1, 1))
     args = (t(Rt), k, tr * scale, t(X), t(Y), t(Z), t(uL32), t(vL32), t(uR32), t(vR32))
     plain = ops.score_hypotheses(*args, thresh=thresh, cap=n, n_host=n, want_masks=False, fast=False)
-    for impl in ("wide", "split", "f64", "bf16"):
-        os.environ["SLAM_SCORE_IMPL"] = impl
+    for impl in ("wide", "split", "f64"):
+        _lib.select_kernels(score=impl)
         fast = ops.score_hypotheses(*args, thresh=thresh, cap=n, n_host=n, want_masks=False, fast=True)
         torch.cuda.synchronize()
         diff = int((fast != plain).sum())
