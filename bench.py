@@ -29,7 +29,11 @@ sys.path.insert(0, ROOT)
 
 INT_VALU_PEAK_TOPS = 78.6   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz simple int32 ops (nominal)
 INT_VALU_MEASURED_MIX_TOPS = 50.3  # tools/valu_peak.hip on the box: v_xor_b32 + v_bcnt_u32_b32 (bcnt is half rate)
-FP4_MFMA_PEAK_TOPS = 10000.0       # dense fp4/fp6 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4) = 4 x bf16
+FP4_MFMA_PEAK_TOPS = 10000.0       # dense fp4/fp6 MFMA (v_mfma_f32_32x32x64_f8f6f4) = 4 x bf16
+# tools/mfma_fp4_rate.hip on the box, bare MFMA loop, 2 waves per SIMD: the instruction takes 33 cycles whatever it is
+# fed, the clock the chip holds does not: 2.41 GHz on zero operands (9933 TOP/s), 2.09 GHz on operands with the
+# matcher's statistics (8454), 1.71 GHz on dense random operands (6771)
+FP4_MFMA_MEASURED_MATCHER_OPERANDS_TOPS = 8454.0
 HBM_PEAK_GBS = 8000.0
 FP64_VALU_PEAK_TF = 78.6    # 256 CU x 64 fp64 FMA lanes/clk x 2 flop x 2.4 GHz
 FP32_VALU_PEAK_TF = 157.3   # plain (unpacked) fp32 FMA issues at twice the fp64 rate
@@ -508,6 +512,8 @@ def main():
         "peak": INT_VALU_PEAK_TOPS if valu_impl else mfma_peak,
         "unit": "Tint32-op/s" if valu_impl else mfma_unit,
         "frac": (valu_tops / INT_VALU_PEAK_TOPS) if valu_impl else (mfma_tops / mfma_peak),
+        "measured_rate_of_a_bare_mfma_loop_on_these_operands": None if valu_impl else FP4_MFMA_MEASURED_MATCHER_OPERANDS_TOPS,
+        "frac_of_measured_rate": None if valu_impl else mfma_tops / FP4_MFMA_MEASURED_MATCHER_OPERANDS_TOPS,
         "traffic": traffic.get(f"{knn_name}_bytes_per_launch"),
         "avg_launch_ms": match_ms / 2.0,
         "pairs_per_s": match_pairs / (match_ms * 1e-3),
