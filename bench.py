@@ -190,6 +190,85 @@ def sequence_run(a, rank, world, dev, multi, backend, steps, warmup):
     return dt, info
 
 
+def stress_run(dev):
+    """BASELINE configs[4] on this GPU, beside the headline: one GPU's share of the 8000-keypoint
+    sequence (4541 frames over 8 GPUs = 568 frame pairs) through the whole front-end with the
+    device-side RANSAC, and the loop-closure stress -- every one of 228 keyframes (one per 20
+    frames, models/BundleAdjustment.py:205-210) against all keyframes at least 2 keyframes back
+    (30 frames, models/LoopClosure.py:214,234), consensus matching at ratio 0.6 with a
+    500-iteration RANSAC (models/LoopClosure.py:112-139), all pairs in one launch per stage."""
+    import torch
+    from slam_amd import pipeline
+    from slam_amd.synthetic import SyntheticSequence, read_cameras
+    k, m1, m2 = read_cameras()
+    out = {}
+
+    def timed(go, reps):
+        go()
+        torch.cuda.synchronize()
+        best = 1e30
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            go()
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return best
+
+    # ---- one GPU's share of the 8k-keypoint sequence
+    kp, frames = 8000, 569
+    t0 = time.perf_counter()
+    seq = SyntheticSequence(kp, frames)
+    t_gen = time.perf_counter() - t0
+    torch.cuda.reset_peak_memory_stats()
+    fe = pipeline.FrontEnd(k, m1, m2)
+    tb = pipeline.FrameTables.from_frames(seq.frames, dev)
+    ws = fe.prepare(tb, n_hyp=1000)
+    fe.prepare_ransac(ws)
+    dt = timed(lambda: fe.run_ransac(ws, seed=6), 3)
+    P = frames - 1
+    truth = np.stack([seq.relative_pose(p, p + 1) for p in range(P)])
+    out["sequence_share_8k"] = {
+        "workload": f"{P} consecutive frame pairs x {kp} keypoints x 61-byte descriptors (4541 frames over 8 GPUs), "
+                    "1000 device-made hypotheses per pair",
+        "ms_per_pass": 1e3 * dt, "frame_pairs_per_s": P / dt,
+        "descriptor_pairs_per_s": float(2 * P * kp * kp) / dt,
+        "mean_consensus_per_pair": float(ws.cons.count[:P].float().mean().item()),
+        "mean_inlier_ratio": float(ws.ratio[:P].mean().item()),
+        "pose_error_vs_truth_max": float(np.abs(ws.pose.cpu().numpy()[:P].reshape(P, 3, 4) - truth).max()),
+        "host_generate_s": t_gen, "hbm_allocated_GB": torch.cuda.max_memory_allocated() / 1e9}
+    del ws, tb, seq
+    torch.cuda.empty_cache()
+
+    # ---- loop closure: all-vs-keyframe consensus matching
+    n_kf, min_gap, hyp = 228, 2, 500
+    t0 = time.perf_counter()
+    seq = SyntheticSequence(kp, n_kf, step=2.0)
+    t_gen = time.perf_counter() - t0
+    kf = np.arange(n_kf)
+    pairs = np.asarray([(i, j) for i in kf for j in kf if i - j >= min_gap], dtype=np.int64)
+    torch.cuda.reset_peak_memory_stats()
+    fe = pipeline.FrontEnd(k, m1, m2, ratio_thresh=0.6)
+    tb = pipeline.FrameTables.from_frames(seq.frames, dev)
+    ws = fe.prepare(tb, n_hyp=hyp, pairs=pairs)
+    fe.prepare_ransac(ws)
+    dt = timed(lambda: fe.run_ransac(ws, seed=6), 2)
+    P = ws.P
+    n_cons = ws.cons.count.cpu().numpy()[:P]
+    found = ws.found.cpu().numpy()[:P].astype(bool)
+    nL = np.diff(tb.offL).astype(np.float64)
+    desc_pairs = float((nL[pairs[:, 0]] * nL[pairs[:, 1]]).sum() + (nL * np.diff(tb.offR)).sum())
+    out["loop_closure"] = {
+        "workload": f"{n_kf} keyframes x {kp} keypoints, every keyframe against all keyframes >= {min_gap} back = {P} "
+                    f"keyframe pairs, ratio 0.6, {hyp}-iteration device RANSAC each",
+        "s_per_sweep": dt, "keyframe_pairs_per_s": P / dt, "descriptor_pairs_per_s": desc_pairs / dt,
+        "pairs_with_10_consensus_and_a_pose": int((found & (n_cons >= 10)).sum()),
+        "mean_consensus": float(n_cons.mean()), "host_generate_s": t_gen,
+        "hbm_allocated_GB": torch.cuda.max_memory_allocated() / 1e9}
+    del ws, tb, seq
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     a = parse()
     # stdout carries exactly one line, the JSON result: libraries that print to file descriptor 1
@@ -469,6 +548,14 @@ def main():
         except Exception as exc:                              # never lose the headline over the side measurement
             full_info = {"error": repr(exc)}
 
+    # ---- BASELINE configs[4] beside the headline: this GPU's share of the 8k-keypoint sequence, loop-closure sweep
+    stress_info = None
+    if rank == 0 and world == 1 and not multi and os.environ.get("SLAM_BENCH_STRESS", "1") != "0":
+        try:
+            stress_info = stress_run(dev)
+        except Exception as exc:                              # never lose the headline over the side measurement
+            stress_info = {"error": repr(exc)}
+
     if rank != 0:
         if multi:
             dist.destroy_process_group()
@@ -597,6 +684,7 @@ def main():
         "device_ransac": ransac_info,
         "host_fed": ingest_info,
         "full_sequence": full_info,
+        "stress": stress_info,
     }
     if not a.no_cpu_baseline:
         threads = min(16, os.cpu_count() or 1)
