@@ -630,8 +630,8 @@ def main():
         score_roof = {
             "kernel": f"{score_name} (1 launch per step)", "bound": "valu-issue", "achieved": issue,
             "peak": VALU_ISSUE_PEAK_TOPS,
-            "unit": "T VALU lane-instr/s (executed: 26 instructions per evaluation, ISA count; peak = 256 CU x 4 SIMD "
-                    "x 32 lanes x 2.4 GHz)",
+            "unit": "T VALU lane-instr/s (executed: 26 instructions per evaluation, ISA count of the evaluation; "
+                    "SQ_INSTS_VALU in profiles/ gives 27.1 with the loop around it; peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz)",
             "frac": issue / VALU_ISSUE_PEAK_TOPS,
             "instructions_per_evaluation": SCORE_MIXED_VALU_PER_EVAL,
             "measured_v_fma_f32_peak": VALU_FMA32_MEASURED_TOPS,
