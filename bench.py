@@ -12,9 +12,11 @@ The default workload is BASELINE.json configs[1]: consecutive frame pairs at ~2k
 keypoints with a fixed seeded set of 10 000 hypotheses per pair.
 
     python bench.py --gpus N --steps K --warmup W
-Under torch.distributed.run every rank owns its own contiguous frame range (weak
-scaling: P pairs per GPU) and the per-pair inlier tables are gathered to rank 0 over
-RCCL inside the timed region.  Rank 0 prints one JSON line.
+With N > 1 and no torch.distributed environment the script starts N ranks of itself (a child
+`python -m torch.distributed.run`, one rank per GPU) and relays rank 0's line; started under
+torch.distributed.run by someone else it is one of the ranks.  Every rank owns its own
+contiguous frame range (weak scaling: P pairs per GPU) and the per-pair inlier tables are
+gathered to rank 0 over RCCL inside the timed region.  Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -60,6 +62,32 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=128, help="frame pairs timed on the CPU oracle")
     return ap.parse_args()
+
+
+def child_command(n_ranks, argv, port):
+    """The command that runs this script as n_ranks ranks on this node (one process per GPU)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def launch_ranks(n_ranks, argv):
+    """`bench.py --gpus N` typed at a shell, N > 1: start the N ranks as a CHILD process (this
+    process has not touched a GPU and never replaces itself), pass its stderr through, relay the
+    one JSON line rank 0 wrote to stdout and exit with the child's code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(child_command(n_ranks, argv, port), stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    for ln in lines[-1:]:
+        print(ln, flush=True)
+    if proc.returncode == 0 and not lines:
+        print("[bench] the ranks exited without a result line", file=sys.stderr)
+        return 1
+    return proc.returncode
 
 
 def cpu_baseline(seq, Rt_host, n_pairs, threads):
@@ -183,6 +211,7 @@ def sequence_run(a, rank, world, dev, multi, backend, steps, warmup):
         "track_store_equals_host_replay": (bool(np.array_equal(db.get_track_length_data(), host_db.get_track_length_data()))
                                            if host_db is not None else None),
         "host_generate_s": t_gen, "hbm_allocated_GB": torch.cuda.max_memory_allocated() / 1e9,
+        "gather_bytes_per_rank": int(lanes[0][0].layout.nbytes),
         "note": "gpu_ms_per_pass: every stage incl. RANSAC and the gather, inputs resident; track_store_ms: track ids on "
                 "the GPU, copy to the host, array-backed store answering one bundle window's queries; "
                 "host_row_replay_ms: the row-by-row replay it replaces",
@@ -271,6 +300,12 @@ def stress_run(dev):
 
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != a.gpus:
+        print(f"[bench] --gpus {a.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks",
+              file=sys.stderr)
+        sys.exit(2)
     # stdout carries exactly one line, the JSON result: libraries that print to file descriptor 1
     # (RCCL writes a version banner there when a communicator is created) are sent to stderr, and
     # the result line goes to the saved descriptor at the end.
@@ -285,7 +320,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # SLAM_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
     backend = os.environ.get("SLAM_BENCH_BACKEND", "nccl")
-    local = local % max(torch.cuda.device_count(), 1)
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and (n_dev == 0 or world > n_dev):
+        # one rank per GPU or nothing: ranks doubling up on a card would report a scaling curve that is not one
+        print(f"[bench] rank {rank}: {world} ranks asked for, {n_dev} GPUs visible "
+              "(SLAM_BENCH_BACKEND=gloo rehearses the multi-rank path on fewer GPUs)", file=sys.stderr)
+        sys.exit(3)
+    local = local % max(n_dev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # SLAM_BENCH_FORCE_DIST=1 takes the multi-rank path (process group, arena gather, overlap) even
@@ -305,7 +346,11 @@ def main():
         if rank == 0:
             out = {
                 "metric": "stereo frame-pairs/sec (match+triangulate+RANSAC)",
-                "value": (a.frames - 1) * a.steps / dt, "unit": "frame-pairs/s", "n_gpus": world, "steps": a.steps,
+                "value": (a.frames - 1) * a.steps / dt, "unit": "frame-pairs/s", "n_gpus": world,
+                "process_group": {"backend": backend if multi else None, "ranks": dist.get_world_size() if multi else 1,
+                                  "gather_bytes_per_rank_per_step": info.get("gather_bytes_per_rank", 0) if multi else 0,
+                                  "gather_bytes_into_rank0_per_step": info.get("gather_bytes_per_rank", 0) * (world - 1) if multi else 0},
+                "steps": a.steps,
                 "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong",
                 "vs_baseline": None,
                 "dtype": "fp4 MFMA (exact Hamming) matching + f64 triangulation + f32-filtered f64 scoring",
@@ -662,6 +707,9 @@ def main():
         "value": world * P * a.steps / dt,
         "unit": "frame-pairs/s",
         "n_gpus": world,
+        "process_group": {"backend": backend if multi else None, "ranks": dist.get_world_size() if multi else 1,
+                          "gather_bytes_per_rank_per_step": int(ws.layout.nbytes) if multi else 0,
+                          "gather_bytes_into_rank0_per_step": int(ws.layout.nbytes) * (world - 1) if multi else 0},
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps,
