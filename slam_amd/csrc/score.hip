@@ -747,6 +747,8 @@ extern "C" int slam_score_hypotheses_static(const double *Rt, int n_sets, int H,
                                             const int32_t *n_dev, int n_host, double thresh, int32_t *counts,
                                             void *stream)
 {
+    // Contract: every size check below comes BEFORE the first HIP call (scratch_for_current_device), so a
+    // refused call touches no device and the refusals can be exercised on a machine without a GPU.
     if (n_sets < 0 || H < 0 || cap < 0)
         return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses_static: negative size");
     const long long need = (long long)SLAM_SCORE_WORK_PER_POINT * n_sets * (cap > 1 ? cap : 1);

@@ -10,6 +10,7 @@
  */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -355,7 +356,12 @@ done:
 
 /* chain_poses(rel float64 [P,12], first float64 [12], ex float64 [P+1,12] out, cam float64 [P+1,3] out)
  * Global extrinsics and camera centres from relative poses (utils/utils.py:283-288):
- * R' = R R_prev, t' = R t_prev + t, centre = -R'^T t'; sums taken left to right. */
+ * R' = R R_prev, t' = R t_prev + t, centre = -R'^T t'.
+ * The reference takes these products with numpy's `@`, i.e. with whatever its BLAS does; the sums
+ * below are taken in the order numpy 2.2 / OpenBLAS 0.3.29 (x86-64 kernels with FMA) takes them for
+ * these shapes -- matrix product: fma(a2,b2, fma(a1,b1, a0*b0)); matrix (row stride 4) times vector:
+ * fma(a2,b2, fma(a0,b0, a1*b1)); negated transpose times vector: the first form again.  The caller
+ * checks the result against numpy's own on a sample before trusting it (sharding.chain_poses). */
 static PyObject *chain_poses(PyObject *Py_UNUSED(self), PyObject *args)
 {
     Py_buffer rel_b, first_b, ex_b, cam_b;
@@ -379,11 +385,11 @@ static PyObject *chain_poses(PyObject *Py_UNUSED(self), PyObject *args)
             double *o = ex + 12 * (p + 1), *c = cam + 3 * (p + 1);
             for (int i = 0; i < 3; ++i) {
                 for (int j = 0; j < 3; ++j)
-                    o[4 * i + j] = r[4 * i] * e[j] + r[4 * i + 1] * e[4 + j] + r[4 * i + 2] * e[8 + j];
-                o[4 * i + 3] = (r[4 * i] * e[3] + r[4 * i + 1] * e[7] + r[4 * i + 2] * e[11]) + r[4 * i + 3];
+                    o[4 * i + j] = fma(r[4 * i + 2], e[8 + j], fma(r[4 * i + 1], e[4 + j], r[4 * i] * e[j]));
+                o[4 * i + 3] = fma(r[4 * i + 2], e[11], fma(r[4 * i], e[3], r[4 * i + 1] * e[7])) + r[4 * i + 3];
             }
             for (int j = 0; j < 3; ++j)
-                c[j] = -o[j] * o[3] - o[4 + j] * o[7] - o[8 + j] * o[11];
+                c[j] = fma(-o[8 + j], o[11], fma(-o[4 + j], o[7], (-o[j]) * o[3]));
         }
     }
     result = Py_None;

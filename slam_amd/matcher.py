@@ -351,12 +351,17 @@ class Matcher:
             for c, m in enumerate(row[:2]):
                 idx[i, c], dist[i, c] = m.trainIdx, m.distance
         found = idx >= 0
-        if (dist[found] == np.floor(dist[found])).all() and (dist[found] < 2 ** 31).all():   # Hamming: integers
+        # the norm follows the descriptor type, as it does for cv2's matchers on this path: binary
+        # descriptors (uint8) are compared with a Hamming norm, whose distances are integers; anything
+        # else is a float norm (cv2.BFMatcher() on SIFT), held as float32 like cv2 holds it
+        binary = np.asarray(q_dsc).dtype == np.uint8 and np.asarray(t_dsc).dtype == np.uint8
+        d_found = dist[found]
+        if binary and np.isfinite(d_found).all() and (d_found == np.floor(d_found)).all() and (d_found < 2 ** 31).all():
             out = np.full(dist.shape, np.iinfo(np.int32).max, np.int32)
-            out[found] = dist[found].astype(np.int32)
-        else:                                     # a float norm (cv2.BFMatcher() on SIFT): float32, as cv2 holds it
+            out[found] = d_found.astype(np.int32)
+        else:
             out = np.full(dist.shape, np.finfo(np.float32).max, np.float32)
-            out[found] = dist[found].astype(np.float32)
+            out[found] = d_found.astype(np.float32)
         return idx, out, None
 
     def find_matching_features(self, with_significance_test=False, debug=False, row_thresh=None):
@@ -414,7 +419,8 @@ class Matcher:
         for i, pair in enumerate(matches):
             m, nn = pair  # ValueError on a short list, like the reference
             d0, d1 = m.distance, nn.distance
-            if exact and d0 == int(d0) and d1 == int(d1) and 0 <= d0 < 2 ** 31 and 0 <= d1 < 2 ** 31:
+            # (a non-finite distance from a plugged-in float matcher must reach the plain compare below, not int())
+            if exact and 0 <= d0 < 2 ** 31 and 0 <= d1 < 2 ** 31 and d0 == int(d0) and d1 == int(d1):
                 idx[i] = (m.trainIdx, nn.trainIdx)
                 dist[i] = (int(d0), int(d1))
             else:

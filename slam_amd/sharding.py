@@ -180,11 +180,7 @@ class TableGather:
         return res
 
 
-def chain_poses(rel_poses, first=None):
-    """Global extrinsics and camera centres from relative poses, as the reference
-    composes them (utils/utils.py:283-288): R' = R @ R_prev, t' = R @ t_prev + t,
-    centre = -R'^T t'.  rel_poses: [P,3,4]; first: extrinsic of frame 0 (the reference
-    starts at M1, utils/utils.py:244-245; default [I|0]).  Returns ([P+1,3,4], [P+1,3])."""
+def _chain_poses_numpy(rel_poses, first=None):
     n = rel_poses.shape[0] + 1
     ex = np.zeros((n, 3, 4))
     ex[0] = np.hstack([np.eye(3), np.zeros((3, 1))]) if first is None else first
@@ -197,6 +193,57 @@ def chain_poses(rel_poses, first=None):
         ex[i + 1] = np.hstack((new_R, new_t[:, None]))
         cam[i + 1] = -new_R.T @ new_t
     return ex, cam
+
+
+def _chain_poses_native(rel_poses, first=None):
+    from .track_database import _native
+    P = rel_poses.shape[0]
+    ex, cam = np.empty((P + 1, 3, 4)), np.empty((P + 1, 3))
+    start = np.hstack([np.eye(3), np.zeros((3, 1))]) if first is None else np.asarray(first, dtype=np.float64)
+    _native.chain_poses(np.ascontiguousarray(rel_poses, dtype=np.float64).reshape(-1, 12),
+                        np.ascontiguousarray(start.reshape(12)), ex, cam)
+    return ex, cam
+
+
+_native_chain_ok = None
+
+
+def native_chain_matches_numpy():
+    """Whether the C helper's pose chain is bit-identical to numpy's `@` chain on this host.  numpy's
+    small products go through its BLAS, whose summation order (and use of fused multiply-add) is a
+    property of that build and CPU, so the helper -- written to the order numpy 2.2 / OpenBLAS takes
+    on x86-64 with FMA -- is trusted only after reproducing numpy on a seeded sample of 64 poses
+    (every one of the 960 sums would have to round alike by chance otherwise).  Checked once."""
+    global _native_chain_ok
+    if _native_chain_ok is None:
+        from .track_database import _native
+        if _native is None:
+            _native_chain_ok = False
+        else:
+            from .synthetic import rodrigues_batch
+            rng = np.random.default_rng(20240607)
+            rel = np.empty((64, 3, 4))
+            rel[:, :, :3] = rodrigues_batch(rng.normal(size=(64, 3)) * 0.2)
+            rel[:, :, 3] = rng.normal(size=(64, 3))
+            first = np.hstack([rodrigues_batch(rng.normal(size=(1, 3)))[0], rng.normal(size=(3, 1))])
+            a, b = _chain_poses_numpy(rel, first), _chain_poses_native(rel, first)
+            _native_chain_ok = bool(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]))
+    return _native_chain_ok
+
+
+def chain_poses(rel_poses, first=None):
+    """Global extrinsics and camera centres from relative poses, as the reference
+    composes them (utils/utils.py:283-288): R' = R @ R_prev, t' = R @ t_prev + t,
+    centre = -R'^T t'.  rel_poses: [P,3,4]; first: extrinsic of frame 0 (the reference
+    starts at M1, utils/utils.py:244-245; default [I|0]).  Returns ([P+1,3,4], [P+1,3]).
+    The loop runs in the C helper when that reproduces numpy's products bit for bit on this
+    host (native_chain_matches_numpy), else in numpy as the reference writes it: every path
+    through this module -- host replay, device track arrays, the batched VO drivers -- gets
+    the same poses either way."""
+    rel_poses = np.asarray(rel_poses, dtype=np.float64).reshape(-1, 3, 4)
+    if rel_poses.shape[0] > 8 and native_chain_matches_numpy():
+        return _chain_poses_native(rel_poses, first)
+    return _chain_poses_numpy(rel_poses, first)
 
 
 def replay_tracks(shards, first_frame=0, first=None):
@@ -249,17 +296,19 @@ def replay_tracks_device(shards, first_frame=0, first=None, device=None):
     replay_tracks; falls back to it when the tables hold something the kernels do not cover (two rows
     of one pair continuing the same track).  Tables on the host (gloo rehearsal) are uploaded."""
     from . import ops
-    from .track_database import ArrayTrackDatabase, _native
+    from .track_database import ArrayTrackDatabase
     shards = [sh for sh in shards]
     if device is None:
         cuda = [sh["rows"].device for sh in shards if sh["rows"].is_cuda]
         device = cuda[0] if cuda else torch.device("cuda", torch.cuda.current_device())
     up = lambda t: t if t.device == device else t.to(device)
+    # only the valid rows of every shard (the tables carry unused capacity behind them, whose contents
+    # are stale or uninitialised), back to back: one size read per shard
+    totals = [int(sh["n_inl"].sum().item()) for sh in shards]
     if len(shards) == 1:
-        n_inl_d, rows_d, loc_d = up(shards[0]["n_inl"]), up(shards[0]["rows"]), up(shards[0]["loc"])
+        t = totals[0]
+        n_inl_d, rows_d, loc_d = up(shards[0]["n_inl"]), up(shards[0]["rows"][:t]), up(shards[0]["loc"][:t])
     else:
-        # the valid rows of every shard, back to back (one size read per shard)
-        totals = [int(sh["n_inl"].sum().item()) for sh in shards]
         n_inl_d = torch.cat([up(sh["n_inl"]) for sh in shards])
         rows_d = torch.cat([up(sh["rows"][:t]) for sh, t in zip(shards, totals)])
         loc_d = torch.cat([up(sh["loc"][:t]) for sh, t in zip(shards, totals)])
@@ -273,7 +322,10 @@ def replay_tracks_device(shards, first_frame=0, first=None, device=None):
         kp_cap = int(torch.maximum(rows_d[:, 0].max(), rows_d[:, 2].max()).item()) + 1
     else:
         kp_cap = max(int(k) for k in kp_caps)
-    out = ops.track_assign(rows_d, loc_d, n_inl_d, kp_cap, first_frame)
+    try:
+        out = ops.track_assign(rows_d, loc_d, n_inl_d, kp_cap, first_frame)
+    except ops._lib.SlamError:
+        return replay_tracks(shards, first_frame, first)      # e.g. keypoint indices beyond what the kernels index
     summary = out["summary"].cpu().numpy()
     T, n_tracks, N, longest, flags = (int(v) for v in summary[:5])
     if flags:
@@ -285,14 +337,9 @@ def replay_tracks_device(shards, first_frame=0, first=None, device=None):
                             max_length=longest)
     n_inl = np.concatenate([sh["n_inl"].cpu().numpy() for sh in shards]).astype(np.int64)
     n_cons = np.concatenate([sh["n_cons"].cpu().numpy() for sh in shards]).astype(np.int64)
-    db.set_frame_records(np.where(n_cons > 0, n_inl / np.maximum(n_cons, 1), 0.0), n_inl.astype(np.float64))
-    poses = np.ascontiguousarray(np.concatenate([sh["pose"].cpu().numpy().reshape(-1, 12) for sh in shards]))
-    if _native is not None:
-        ex, cam = np.empty((P + 1, 3, 4)), np.empty((P + 1, 3))
-        start = np.hstack([np.eye(3), np.zeros((3, 1))]) if first is None else np.asarray(first, dtype=np.float64)
-        _native.chain_poses(poses, np.ascontiguousarray(start.reshape(12)), ex, cam)
-    else:
-        ex, cam = chain_poses(poses.reshape(-1, 3, 4), first=first)
+    db.set_frame_records(np.where(n_cons > 0, n_inl / np.maximum(n_cons, 1), 0.0), n_inl)
+    poses = np.concatenate([sh["pose"].cpu().numpy().reshape(-1, 12) for sh in shards])
+    ex, cam = chain_poses(poses.reshape(-1, 3, 4), first=first)
     db.set_ex_matrices(ex)
     db.set_ex_camera_positions(cam)
     return db
@@ -310,7 +357,7 @@ def _replay_into(db, poses, shards, frame):
         for p in range(n_inl.shape[0]):
             m = int(n_inl[p])
             db.add_inliers_ratio(frame, (m / int(n_cons[p])) if n_cons[p] else 0.0)
-            db.add_num_matches(frame, num_matches=float(m))
+            db.add_num_matches(frame, num_matches=np.float64(m))   # np.sum of find_supporters' float64 0/1 array (utils/utils.py:279,282,390)
             poses.append(pose[p])
             frame += 1
     return frame

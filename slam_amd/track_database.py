@@ -506,7 +506,8 @@ class ArrayTrackDatabase(TrackDatabase):
         a = self._arrays
         frames = range(a["first"], a["first"] + a["P"])
         self._frame_id_to_inliers_ratio.update(zip(frames, np.asarray(ratios, dtype=np.float64).tolist()))
-        self._frame_id_to_num_matches.update(zip(frames, np.asarray(num_matches, dtype=np.float64).tolist()))
+        # np.float64 values: the reference stores np.sum of find_supporters' float64 0/1 array (utils/utils.py:279,282,390)
+        self._frame_id_to_num_matches.update(zip(frames, np.asarray(num_matches, dtype=np.float64)))
 
     # -- queries from the arrays -----------------------------------------------------------------
     def get_track_data(self, track_id):

@@ -65,7 +65,7 @@ def drive(RefDB, matcher, first_frame, rows, n_inl, n_cons):
         tuples = [(int(r[0]), int(r[1]), int(r[2]), int(r[3]), None) for r in rows[off:off + m]]
         db.update_tracks_from_frame(matcher, frame, tuples)
         db.add_inliers_ratio(frame, (m / n_cons[p]) if n_cons[p] else 0.0)
-        db.add_num_matches(frame, num_matches=float(m))
+        db.add_num_matches(frame, num_matches=np.float64(m))     # np.sum of a float64 0/1 array (utils/utils.py:279,390)
         off += m
     return db
 

@@ -160,6 +160,36 @@ def test_pose_chaining_matches_reference_formula():
         assert np.allclose(cam[i + 1], -R.T @ t)
 
 
+def test_every_route_chains_poses_bit_for_bit_like_numpy():
+    """chain_poses is the one place poses are chained (host replay, device track arrays, batched VO).  It
+    runs in the C helper only where that reproduces numpy's `@` products -- the reference's arithmetic
+    (utils/utils.py:283-288) -- bit for bit; over a 4541-frame sequence any other summation order shows."""
+    rng = np.random.default_rng(5)
+    P = 4540
+    rel = np.empty((P, 3, 4))
+    rel[:, :, :3] = np.stack([rodrigues(v) for v in rng.normal(size=(P, 3)) * 0.01])
+    rel[:, :, 3] = rng.normal(size=(P, 3)) * 0.1 + [0, 0, -0.8]
+    k, m1, m2 = read_cameras()
+    ex, cam = sharding.chain_poses(rel, first=m1)
+    ex_np, cam_np = sharding._chain_poses_numpy(rel, first=m1)
+    assert np.array_equal(ex, ex_np) and np.array_equal(cam, cam_np)
+    if sharding.native_chain_matches_numpy():
+        ex_c, cam_c = sharding._chain_poses_native(rel, first=m1)
+        assert np.array_equal(ex_c, ex_np) and np.array_equal(cam_c, cam_np)
+
+
+def test_replayed_frame_records_have_the_reference_types():
+    """num_matches is np.sum of find_supporters' float64 0/1 array in the reference (utils/utils.py:279,282,390)."""
+    import torch
+    sh = dict(n_inl=torch.tensor([2, 0], dtype=torch.int32), n_cons=torch.tensor([3, 0], dtype=torch.int32),
+              pose=torch.eye(3, 4, dtype=torch.float64).reshape(1, 12).repeat(2, 1),
+              rows=torch.tensor([[0, 1, 2, 3], [4, 5, 6, 7]], dtype=torch.int32), loc=torch.zeros((2, 6)))
+    db = sharding.replay_tracks([sh])
+    nm = db.get_num_matches_per_frame()
+    assert [type(v) for v in nm.values()] == [np.float64, np.float64] and list(nm.values()) == [2.0, 0.0]
+    assert db.get_inliers_ratio_per_frame() == {0: 2 / 3, 1: 0.0}
+
+
 def test_shard_pairs_cover_the_sequence():
     for n_frames, world in ((4541, 8), (2560, 3), (5, 8), (1, 2), (2, 2)):
         sh = sharding.shard_pairs(n_frames, world)

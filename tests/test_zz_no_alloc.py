@@ -92,7 +92,12 @@ def test_static_workspace_scoring_matches_the_workspace_entry_point(device):
 
 
 def test_static_workspace_scoring_refuses_what_does_not_fit():
-    lib = _lib.load()
+    """No GPU needed: the entry point checks its sizes before its first HIP call.  The library itself
+    still has to load, which needs the HIP runtime's shared objects on the machine."""
+    try:
+        lib = _lib.load()
+    except (OSError, _lib.SlamError) as exc:
+        pytest.skip(f"libslam_amd.so does not load here: {exc}")
     null = ctypes.c_void_p(0)
     K9 = (ctypes.c_double * 9)(700.0, 0.0, 600.0, 0.0, 700.0, 180.0, 0.0, 0.0, 1.0)
     t3 = (ctypes.c_double * 3)(-0.5, 0.0, 0.0)
