@@ -9,7 +9,8 @@ same two jobs are done here in numpy:
                first three correspondences, the fourth picks among the up-to-four
                solutions -- the role AP3P's fourth point plays in cv2;
 * `refine_pnp`: Levenberg-Marquardt on the left-image reprojection error over all
-               given correspondences, started from a supplied pose.
+               given correspondences, started from a supplied pose (optionally on both
+               images' residuals: not the reference's cost, kept to study its drift).
 
 They are small scalar host code (a few poses per frame); every hypothesis they produce
 is scored on the GPU.  Their outputs agree with cv2's to solver tolerance, not bit for
@@ -121,8 +122,12 @@ def _exp_so3(w):
     return np.eye(3) + np.sin(th) / th * Kx + (1 - np.cos(th)) / (th * th) * (Kx @ Kx)
 
 
-def refine_pnp(points_3d, points_2d, K, Rt0, iterations=30):
-    """Levenberg-Marquardt on left-image reprojection error from the initial pose Rt0."""
+def refine_pnp(points_3d, points_2d, K, Rt0, iterations=30, points_2d_right=None, t_right=None):
+    """Levenberg-Marquardt on left-image reprojection error from the initial pose Rt0 -- the cost
+    cv2.solvePnP(SOLVEPNP_ITERATIVE) minimises for the reference (utils/utils.py:452,481-485: left
+    keypoints only).  Option, off by default and not the reference's behaviour: with points_2d_right
+    [n,2] and t_right [3] (the right camera's offset, M2[:, 3]) the right image's residuals are
+    minimised as well (4 per point)."""
     X = np.asarray(points_3d, dtype=np.float64).reshape(-1, 3)
     uv = np.asarray(points_2d, dtype=np.float64).reshape(-1, 2)
     if X.shape[0] < 3 or Rt0 is None:
@@ -130,12 +135,19 @@ def refine_pnp(points_3d, points_2d, K, Rt0, iterations=30):
     K = np.asarray(K, dtype=np.float64)
     fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
     R, t = np.array(Rt0[:, :3], dtype=np.float64), np.array(Rt0[:, 3], dtype=np.float64)
+    stereo = points_2d_right is not None
+    if stereo:
+        uvr = np.asarray(points_2d_right, dtype=np.float64).reshape(-1, 2)
+        tr = np.asarray(t_right, dtype=np.float64).reshape(3)
+    cams = [(uv, np.zeros(3))] + ([(uvr, tr)] if stereo else [])
 
     def residual(R, t):
         Y = X @ R.T + t
-        z = Y[:, 2]
-        r = np.stack([fx * Y[:, 0] / z + cx - uv[:, 0], fy * Y[:, 1] / z + cy - uv[:, 1]], axis=1)
-        return Y, r
+        cols = []
+        for obs, off in cams:
+            Yc = Y + off
+            cols += [fx * Yc[:, 0] / Yc[:, 2] + cx - obs[:, 0], fy * Yc[:, 1] / Yc[:, 2] + cy - obs[:, 1]]
+        return Y, np.stack(cols, axis=1)
 
     lam = 1e-3
     Y, r = residual(R, t)
@@ -143,21 +155,23 @@ def refine_pnp(points_3d, points_2d, K, Rt0, iterations=30):
     if not np.isfinite(cost):
         return None
     for _ in range(iterations):
-        z = Y[:, 2]
         n = X.shape[0]
-        J = np.zeros((n, 2, 6))
-        # d(proj)/dY
-        du = np.stack([fx / z, np.zeros(n), -fx * Y[:, 0] / (z * z)], axis=1)
-        dv = np.stack([np.zeros(n), fy / z, -fy * Y[:, 1] / (z * z)], axis=1)
+        J = np.zeros((n, 2 * len(cams), 6))
         # Y' = exp(w) Y + d  ->  dY/dw = -[Y]x, dY/dd = I
         Yx = np.zeros((n, 3, 3))
         Yx[:, 0, 1], Yx[:, 0, 2] = -Y[:, 2], Y[:, 1]
         Yx[:, 1, 0], Yx[:, 1, 2] = Y[:, 2], -Y[:, 0]
         Yx[:, 2, 0], Yx[:, 2, 1] = -Y[:, 1], Y[:, 0]
-        J[:, 0, :3] = -np.einsum("ni,nij->nj", du, Yx)
-        J[:, 1, :3] = -np.einsum("ni,nij->nj", dv, Yx)
-        J[:, 0, 3:] = du
-        J[:, 1, 3:] = dv
+        for c, (_, off) in enumerate(cams):
+            Yc = Y + off
+            z = Yc[:, 2]
+            # d(proj)/dY
+            du = np.stack([fx / z, np.zeros(n), -fx * Yc[:, 0] / (z * z)], axis=1)
+            dv = np.stack([np.zeros(n), fy / z, -fy * Yc[:, 1] / (z * z)], axis=1)
+            J[:, 2 * c, :3] = -np.einsum("ni,nij->nj", du, Yx)
+            J[:, 2 * c + 1, :3] = -np.einsum("ni,nij->nj", dv, Yx)
+            J[:, 2 * c, 3:] = du
+            J[:, 2 * c + 1, 3:] = dv
         Jm = J.reshape(-1, 6)
         g = Jm.T @ r.reshape(-1)
         Hm = Jm.T @ Jm

@@ -66,7 +66,7 @@ class Frame:
 
 class SyntheticSequence:
     def __init__(self, n_kp, n_frames, seed=SEED, desc_bytes=61, flip=0.08, true_frac=0.6, noise=0.3,
-                 step=0.8, yaw_sigma_deg=0.5):
+                 step=0.8, yaw_sigma_deg=0.5, keep_world=False):
         self.n_kp, self.n_frames, self.seed = int(n_kp), int(n_frames), int(seed)
         self.desc_bytes, self.flip, self.true_frac, self.noise = int(desc_bytes), flip, true_frac, noise
         self.step, self.yaw_sigma = step, np.deg2rad(yaw_sigma_deg)
@@ -75,6 +75,7 @@ class SyntheticSequence:
         self.used_bits = 486 if desc_bytes == 61 else 8 * desc_bytes
         self._tail_mask = np.uint8(0xFF >> (8 * desc_bytes - self.used_bits))
         self.frames = []
+        self._world = [] if keep_world else None      # every 3-D point ever spawned, by id (world_points)
         self._generate()
 
     # -- helpers -----------------------------------------------------------
@@ -148,6 +149,8 @@ class SyntheticSequence:
                 prio = np.concatenate([prio, rng.random(need)])
                 ids = np.concatenate([ids, np.arange(next_id, next_id + need)])
                 next_id += need
+                if self._world is not None:
+                    self._world.append(neww)
                 Xc = np.concatenate([Xc, newc], axis=0)
                 nuL, nuR, nv, _ = self._project(newc)
                 uL, uR, v = np.concatenate([uL, nuL]), np.concatenate([uR, nuR]), np.concatenate([v, nv])
@@ -174,6 +177,14 @@ class SyntheticSequence:
             self.frames.append(Frame(kpL, kpR, descL, descR, idL, idR, np.hstack([R, t[:, None]])))
 
     # -- ground truth ------------------------------------------------------
+    def world_points(self, ids):
+        """[n,3] world coordinates of the 3-D points with these ids (Frame.idL / idR >= 0); needs keep_world=True."""
+        if self._world is None:
+            raise ValueError("SyntheticSequence(..., keep_world=True) keeps the points")
+        if not isinstance(self._world, np.ndarray):
+            self._world = np.concatenate(self._world, axis=0) if self._world else np.zeros((0, 3))
+        return self._world[np.asarray(ids, dtype=np.int64)]
+
     def relative_pose(self, i, j):
         """[3,4] transform taking points from camera i's frame to camera j's."""
         Ri, ti = self.frames[i].Rt[:, :3], self.frames[i].Rt[:, 3]

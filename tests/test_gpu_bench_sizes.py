@@ -207,9 +207,19 @@ def test_full_sequence_length_in_one_batch(device):
     dbd.set_ex_matrices(db.ex_matrices)
     dbd.set_ex_camera_positions(db.camera_positions)
     assert dbd == db                                               # materialises the dict form
-    # dead reckoning over 3.6 km: the chained positions drift with the accumulated yaw error, a few per cent of the path
-    path = 0.8 * P
-    assert np.abs(np.asarray(db.camera_positions) - sharding.chain_poses(gt, first=m1)[1]).max() < 0.1 * path
+    # Dead reckoning over 3.6 km.  Every pair's yaw comes out about 2.2e-5 rad too large (left-image PnP on
+    # triangulated points: a property of the reference's method, see tests/test_gpu_drift.py), so the heading
+    # error grows like b*n and the position error like step*b*n^2/2 = 180 m after 4540 pairs.  Held here: the
+    # bias itself (standard error 8e-7 over this many pairs), that no single pose is off, and that the drift is
+    # what the bias explains -- nothing else contributes.
+    rel = ws.pose.cpu().numpy()[:P].reshape(P, 3, 4)
+    yaw_err = np.array([(a[0, 2] - a[2, 0]) / 2 - (b[0, 2] - b[2, 0]) / 2 for a, b in zip(rel, gt)])   # small angles
+    yaw_bias = float(yaw_err.mean())
+    assert 1.2e-5 < yaw_bias < 3.2e-5 and np.abs(rel - gt).max() < 0.03
+    explained = 0.8 * yaw_bias * P * P / 2.0
+    drift = np.linalg.norm(np.asarray(db.camera_positions) - sharding.chain_poses(gt, first=m1)[1], axis=1).max()
+    print(f"yaw bias {yaw_bias:.3e} rad per pair, drift {drift:.1f} m, explained by the bias {explained:.1f} m")
+    assert 0.6 * explained < drift < 1.4 * explained
 
 
 def test_loop_closure_sweep_against_the_oracle(device):
