@@ -42,13 +42,14 @@ const char *slam_last_error(void);
 /*
  * Kernel variants with identical results, kept for cross-checks and A/B timing (no counterpart in
  * the reference).  Process-wide; -1 leaves a choice as it is.  The defaults come from the
- * environment variables SLAM_KNN_IMPL (fp4 | valu) and SLAM_SCORE_IMPL (auto | f64 | split | wide),
+ * environment variables SLAM_KNN_IMPL (fp4 | valu) and SLAM_SCORE_IMPL (auto | f64 | split | wide | mfma),
  * read once when the library is loaded.
  *   knn:   SLAM_KNN_FP4  Hamming distance on the fp4 matrix cores (default)
  *          SLAM_KNN_VALU xor + popcount on the vector ALU
  *   score: SLAM_SCORE_AUTO  fp32 first-level filter, form chosen from the launch size (default)
  *          SLAM_SCORE_F64   fp64-only filter
  *          SLAM_SCORE_SPLIT / SLAM_SCORE_WIDE  force one form of the fp32 first-level kernel
+ *          SLAM_SCORE_MFMA  fp32 first level with the rigid transform on the fp32 matrix cores
  */
 #define SLAM_KNN_FP4 0
 #define SLAM_KNN_VALU 1
@@ -56,6 +57,7 @@ const char *slam_last_error(void);
 #define SLAM_SCORE_F64 1
 #define SLAM_SCORE_SPLIT 2
 #define SLAM_SCORE_WIDE 3
+#define SLAM_SCORE_MFMA 4
 int slam_select_kernels(int knn, int score);
 
 /*

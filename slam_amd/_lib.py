@@ -134,7 +134,7 @@ def check(status, what):
 
 
 KNN_VARIANTS = {"fp4": 0, "valu": 1}
-SCORE_VARIANTS = {"auto": 0, "mixed": 0, "f64": 1, "split": 2, "wide": 3}
+SCORE_VARIANTS = {"auto": 0, "mixed": 0, "f64": 1, "split": 2, "wide": 3, "mfma": 4}
 
 
 def select_kernels(knn=None, score=None):

@@ -29,6 +29,8 @@ int score_from_env()
         return SLAM_SCORE_SPLIT;
     if (v[0] == 'w')
         return SLAM_SCORE_WIDE;
+    if (v[0] == 'm')
+        return SLAM_SCORE_MFMA;
     return SLAM_SCORE_AUTO;
 }
 // the environment is read here, once, when the library is loaded
@@ -46,7 +48,7 @@ extern "C" const char *slam_last_error(void) { return slam::error_buffer(); }
 
 extern "C" int slam_select_kernels(int knn, int score)
 {
-    if (knn > SLAM_KNN_VALU || score > SLAM_SCORE_WIDE)
+    if (knn > SLAM_KNN_VALU || score > SLAM_SCORE_MFMA)
         return slam::fail(SLAM_ERR_BAD_ARG, "slam_select_kernels: unknown variant (%d, %d)", knn, score);
     if (knn >= 0)
         slam::g_knn.store(knn);

@@ -575,6 +575,332 @@ __global__ void __launch_bounds__(256) score_mixed_kernel(const ScoreArgs a)
     }
 }
 
+
+// Matrix-core form of the fp32 first level for rectified stereo: one wavefront scores 32 hypotheses
+// against all points of its set, 32 points at a time.  The rigid transform of a 32 x 32 tile
+// (hypothesis i, point j) -- hz, gx, gy = q . [X Y Z 1] -- and the point-dependent part of the guard
+// band, ca_i*A2_j + cb_i, are seven v_mfma_f32_32x32x2_f32 (exact fp32: each is bit for bit
+// fma(a1,b1, fma(a0,b0, c)), tools/score_mfma_proxy.hip); their results arrive with lane = point
+// column and register = hypothesis row, so the four pixel coordinates of a point are per-lane
+// values loaded once per tile, and what is left for the vector ALU is 16 instructions per
+// evaluation (4 fma residuals, 2 mul + 2 fma squares, add, max, mul, sub, add, fma, cmp, alignbit)
+// instead of 26.  The MFMAs of tile t+1 are issued between the evaluations of tile t (two
+// accumulator sets), the point records arrive through a ring of four register buffers loaded two
+// tiles ahead.
+//
+// NOT the default, and slower than score_mixed_kernel (1.16 against 0.91 ms on 127 sets x 10 000
+// hypotheses x 1190 points): on gfx950 an fp32 MFMA does not run beside fp32 vector instructions,
+// it takes their place -- a wavefront's MFMA plus N v_fma_f32 cost the sum of the two
+// (tools/mfma_f32_coexec.hip; SQ_VALU_MFMA_COEXEC_CYCLES of this kernel is 0), and seven MFMAs per
+// tile cost slightly more vector-pipe time than the 160 fma they replace.  Kept selectable
+// (SLAM_SCORE_MFMA) as a cross-check with identical counts and so that the measurement can be repeated
+// (tools/ab_score.py).
+//
+// Verdicts are the sign bits of d = max(sl, sr) - hz^2, shifted into one word per (lane, register)
+// and counted 32 tiles at a time; an evaluation the filter is not sure of (|d| <= r) gets a 0 bit
+// and is parked as (row, point) in the wavefront's LDS queue, settled with supports() after the loop.
+//
+// Error bound, as for score_mixed_kernel but for this accumulation order: a term of hz passes
+// through at most four fused operations (fma(q1,Y, q0*X), then fma(q3,1, fma(q2,Z, .))) after the
+// two input roundings, six roundings in all; with the roundings of the residuals (one more on the
+// pixel coordinate, two more for the right camera's offset and its sum)
+//     |a^ - a| + |b^ - b|  <=  G + 2.01u (a^ + b^),   G = u * Wb * (Brot*A + T),   Wb = 11.5*Wmax + 6.2
+// (11.34 and 6.01 by the count above, the rest is slack).  The split of G*(a^+b^) into
+// tau/2*(a^+b^)^2 + G^2/(2 tau) holds for every tau > 0: here tau = 2*u*Wb is one value per set, so
+// c1 = tau/2 + 4.03u is a scalar, and ca = u*Wb*Brot^2, cb = u*Wb*T^2 carry the hypothesis.
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+constexpr int MFMA_QUEUE = 512;   // parked evaluations per wavefront before it recounts everything in fp64
+
+struct MfmaTile {
+    f16v Z, X, Y, R;
+};
+
+struct MfmaOps {       // hypothesis-side MFMA operands of a lane (row = lane % 32, k = lane / 32)
+    float z0, z1, x0, x1, y0, y1, r;
+};
+
+// Evaluations V0 .. V0+3 of a tile held by this lane, in two halves written stage by stage across
+// the four (at two wavefronts per SIMD a dependent instruction must not follow its producer
+// directly: the four evaluations are independent chains); the MFMA `MID` is issued between the
+// halves and `END` after the second.  `any` collects the "not sure" lane masks.
+#define SLAM_MFMA_EACH4 _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)
+#define SLAM_MFMA_EVAL4(V0, MID, END)                                                                        \
+    {                                                                                                        \
+        float gxr_[4], dxl_[4], dyl_[4], dxr_[4], dyr_[4], t1_[4], t2_[4], sl_[4], sr_[4], m_[4], w_[4],     \
+            d_[4], e_[4], r_[4];                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        SLAM_MFMA_EACH4 gxr_[i_] = cur.X[V0 + i_] + crx;                                                     \
+        SLAM_MFMA_EACH4 dxl_[i_] = __builtin_fmaf(ul, cur.Z[V0 + i_], -cur.X[V0 + i_]);                      \
+        SLAM_MFMA_EACH4 dyl_[i_] = __builtin_fmaf(vl, cur.Z[V0 + i_], -cur.Y[V0 + i_]);                      \
+        SLAM_MFMA_EACH4 dyr_[i_] = __builtin_fmaf(vr, cur.Z[V0 + i_], -cur.Y[V0 + i_]);                      \
+        SLAM_MFMA_EACH4 dxr_[i_] = __builtin_fmaf(ur, cur.Z[V0 + i_], -gxr_[i_]);                            \
+        SLAM_MFMA_EACH4 t1_[i_] = dyl_[i_] * dyl_[i_];                                                       \
+        SLAM_MFMA_EACH4 t2_[i_] = dyr_[i_] * dyr_[i_];                                                       \
+        SLAM_MFMA_EACH4 sl_[i_] = __builtin_fmaf(dxl_[i_], dxl_[i_], t1_[i_]);                               \
+        MID;                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        SLAM_MFMA_EACH4 sr_[i_] = __builtin_fmaf(dxr_[i_], dxr_[i_], t2_[i_]);                               \
+        SLAM_MFMA_EACH4 w_[i_] = cur.Z[V0 + i_] * cur.Z[V0 + i_];                                            \
+        SLAM_MFMA_EACH4 m_[i_] = fmaxf(sl_[i_], sr_[i_]);                                                    \
+        SLAM_MFMA_EACH4 d_[i_] = m_[i_] - w_[i_];                                                            \
+        SLAM_MFMA_EACH4 e_[i_] = m_[i_] + w_[i_];                                                            \
+        SLAM_MFMA_EACH4 bits[V0 + i_] = __builtin_amdgcn_alignbit(bits[V0 + i_], __float_as_uint(d_[i_]), 31); \
+        SLAM_MFMA_EACH4 r_[i_] = __builtin_fmaf(c1, e_[i_], cur.R[V0 + i_]);                                 \
+        SLAM_MFMA_EACH4 um[V0 + i_] = __ballot(!(fabsf(d_[i_]) > r_[i_]));                                   \
+        SLAM_MFMA_EACH4 any |= um[V0 + i_];                                                                  \
+        END;                                                                                                 \
+    }
+
+// One step of the scoring loop: the 16 evaluations of tile `cur` with the seven MFMAs of the next
+// tile placed between them, one after every 32 vector instructions (an MFMA holds the matrix pipe
+// for 16 passes but the issue port for one; the scheduler is kept from gathering them).
+__device__ __forceinline__ unsigned long long mfma_step(const MfmaTile &cur, MfmaTile &nxt, const MfmaOps &o, float b0,
+                                                        float b1, float b2, float ul, float vl, float ur, float vr,
+                                                        float crx, float c1, unsigned (&bits)[16],
+                                                        unsigned long long (&um)[16])
+{
+    f16v zero;
+#pragma unroll
+    for (int v = 0; v < 16; ++v)
+        zero[v] = 0.0f;
+    unsigned long long any = 0ull;
+    SLAM_MFMA_EVAL4(0, nxt.Z = __builtin_amdgcn_mfma_f32_32x32x2f32(o.z0, b0, zero, 0, 0, 0),
+                    nxt.X = __builtin_amdgcn_mfma_f32_32x32x2f32(o.x0, b0, zero, 0, 0, 0))
+    SLAM_MFMA_EVAL4(4, nxt.Y = __builtin_amdgcn_mfma_f32_32x32x2f32(o.y0, b0, zero, 0, 0, 0),
+                    nxt.R = __builtin_amdgcn_mfma_f32_32x32x2f32(o.r, b2, zero, 0, 0, 0))
+    SLAM_MFMA_EVAL4(8, nxt.Z = __builtin_amdgcn_mfma_f32_32x32x2f32(o.z1, b1, nxt.Z, 0, 0, 0),
+                    nxt.X = __builtin_amdgcn_mfma_f32_32x32x2f32(o.x1, b1, nxt.X, 0, 0, 0))
+    SLAM_MFMA_EVAL4(12, nxt.Y = __builtin_amdgcn_mfma_f32_32x32x2f32(o.y1, b1, nxt.Y, 0, 0, 0), (void)0)
+    __builtin_amdgcn_sched_barrier(0);
+    return any;
+}
+
+__device__ __forceinline__ void mfma_first(MfmaTile &t, const MfmaOps &o, float b0, float b1, float b2)
+{
+    f16v zero;
+#pragma unroll
+    for (int v = 0; v < 16; ++v)
+        zero[v] = 0.0f;
+    t.Z = __builtin_amdgcn_mfma_f32_32x32x2f32(o.z0, b0, zero, 0, 0, 0);
+    t.X = __builtin_amdgcn_mfma_f32_32x32x2f32(o.x0, b0, zero, 0, 0, 0);
+    t.Y = __builtin_amdgcn_mfma_f32_32x32x2f32(o.y0, b0, zero, 0, 0, 0);
+    t.R = __builtin_amdgcn_mfma_f32_32x32x2f32(o.r, b2, zero, 0, 0, 0);
+    t.Z = __builtin_amdgcn_mfma_f32_32x32x2f32(o.z1, b1, t.Z, 0, 0, 0);
+    t.X = __builtin_amdgcn_mfma_f32_32x32x2f32(o.x1, b1, t.X, 0, 0, 0);
+    t.Y = __builtin_amdgcn_mfma_f32_32x32x2f32(o.y1, b1, t.Y, 0, 0, 0);
+}
+
+__global__ void __launch_bounds__(256, 2) score_mfma_kernel(const ScoreArgs a)
+{
+    __shared__ unsigned queue[4][MFMA_QUEUE];
+    __shared__ int rowcnt[4][32];
+    __shared__ unsigned tally[4][16][64];
+    const int set = blockIdx.x / a.blocks_per_set;
+    const int blk = blockIdx.x - set * a.blocks_per_set;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63u), col = lane & 31;
+    const bool hi = lane >= 32;
+    const int h_base = blk * 128 + wave * 32;
+    if (h_base >= a.H || (a.skip && a.skip[set]))
+        return;   // no block-wide barrier below: every wavefront is on its own
+    const int h = h_base + col;
+    const bool live = h < a.H;
+    const double *hdr = score_hdr(a) + SCORE_HDR * set;
+    const double Amax = hdr[0], Umax = hdr[1], Wmax = hdr[2];
+    const double *pose = a.Rt + ((size_t)set * a.Hs + (live ? h : a.H - 1)) * 12;
+
+    // ---- per-set constants and this lane's hypothesis (row = col) -------------------------------
+    const double fx = a.K.m[0], fy = a.K.m[4], cx = a.K.m[2], cy = a.K.m[5], thr = a.thresh;
+    const double sfx = fx / thr, sfy = fy / thr;
+    const double u24 = 5.9604644775390625e-08;
+    const double Wb = 11.5 * Wmax + 6.2;
+    const double tau = 2.0 * u24 * Wb;
+    const float c1 = (float)((0.5 * tau + 4.03 * u24) * 1.001);
+    const float crx = (float)(sfx * a.tr.v[0]);
+    const double mag = fabs(fx) + fabs(fy) + fabs(cx) + fabs(cy) + Umax + fabs(thr);
+    const bool set_ok = (thr > 0.0) && (mag / thr < 262144.0) && (Wmax >= 0.015625) && (Wmax < 262144.0) &&
+                        (fabs(cx) <= 64.0 * thr * Wmax) && (fabs(cy) <= 64.0 * thr * Wmax) && (tau < 0.125) &&
+                        (Amax < 1e18) && (fabs(sfx) < 1e18) && (fabs(sfy) < 1e18) && (fabs(a.tr.v[0]) < 1e18);
+    double rt[12];
+#pragma unroll
+    for (int c = 0; c < 12; c += 2) {
+        const double2 v = *reinterpret_cast<const double2 *>(pose + c);
+        rt[c] = v.x;
+        rt[c + 1] = v.y;
+    }
+    bool dead = !live;   // a pose with a NaN or Inf entry supports nothing (see score_mixed_kernel)
+#pragma unroll
+    for (int c = 0; c < 12; ++c)
+        dead = dead || !(fabs(rt[c]) < __builtin_inf());
+    double Brot = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            Brot = fmax(Brot, fabs(rt[4 * r + c]));
+    const double T = fmax(fmax(fabs(rt[3]), fabs(rt[7])), fabs(rt[11])) + a.trmax;
+    const double cad = u24 * Wb * Brot * Brot * 1.001;
+    const double cbd = u24 * Wb * T * T * 1.001 + 1e-30;
+    const bool ok = set_ok && (T < 1e18) && (Brot < 1e18) && (cad < 1e30) && (cbd < 1e30);
+    // rows that take no part in the fp32 stage (dead, or to be recounted in fp64) get operands that
+    // keep them quiet: everything 0 and a negative bound, so that they are always "sure" and "out"
+    const bool quiet = dead || !ok;
+    MfmaOps ops;
+    ops.z0 = quiet ? 0.0f : (float)(hi ? rt[9] : rt[8]);
+    ops.z1 = quiet ? 0.0f : (float)(hi ? rt[11] : rt[10]);
+    ops.x0 = quiet ? 0.0f : (float)(sfx * (hi ? rt[1] : rt[0]));
+    ops.x1 = quiet ? 0.0f : (float)(sfx * (hi ? rt[3] : rt[2]));
+    ops.y0 = quiet ? 0.0f : (float)(sfy * (hi ? rt[5] : rt[4]));
+    ops.y1 = quiet ? 0.0f : (float)(sfy * (hi ? rt[7] : rt[6]));
+    ops.r = quiet ? (hi ? -1.0f : 0.0f) : (float)(hi ? cbd : cad);
+    const unsigned dead_rows = (unsigned)__ballot(dead);                 // bit i = row i (lanes 0..31)
+    unsigned full_rows = (unsigned)__ballot(!dead && !ok);               // rows recounted in fp64
+
+    int n = a.n_dev ? a.n_dev[set] : a.n_host;
+    n = min(max(n, 0), a.cap);
+    n = __builtin_amdgcn_readfirstlane(n);
+    const float4 *__restrict__ recs32 =
+        reinterpret_cast<const float4 *>(score_recs32(a) + (size_t)SCORE_REC32 * ((size_t)set * a.cap));
+    const double *__restrict__ recs64 = score_recs64(a) + (size_t)SCORE_REC * ((size_t)set * a.cap);
+    const int n_tiles = (n + 31) >> 5;
+
+    unsigned bits[16];
+    unsigned long long um[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        bits[v] = 0u;
+        tally[wave][v][lane] = 0u;
+    }
+    int qn = 0;   // wave-uniform number of parked evaluations (may exceed MFMA_QUEUE: then everything is recounted)
+
+    auto load = [&](int tile, float4 &ra, float4 &rb) __attribute__((always_inline)) {
+        const float4 *p = recs32 + 2 * (size_t)min(tile * 32 + col, n - 1);
+        ra = p[0];
+        rb = p[1];
+    };
+    // park the evaluations of tile `tile` the filter was not sure of
+    auto park = [&](int tile, unsigned long long valid) __attribute__((always_inline)) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const unsigned long long m = um[v] & valid;
+            if (m != 0ull) {
+                const int row = 8 * (v >> 2) + (v & 3) + (hi ? 4 : 0);
+                if ((m >> lane) & 1ull) {
+                    bits[v] &= ~1u;
+                    const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                                          __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (slot < MFMA_QUEUE)
+                        queue[wave][slot] = ((unsigned)(tile * 32 + col) << 5) | (unsigned)row;
+                }
+                qn += __popcll(m);
+            }
+        }
+    };
+    auto finish = [&](int tile, unsigned long long any) __attribute__((always_inline)) {
+        const int left = n - tile * 32;                       // points of this tile
+        if (__builtin_expect(left < 32, 0)) {
+            // the last, partial tile: lanes past the end evaluated a clamped duplicate; drop their bits
+            const unsigned long long half_mask = (1ull << left) - 1ull;
+            const unsigned long long valid = half_mask | (half_mask << 32);
+            if (!((valid >> lane) & 1ull)) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    bits[v] &= ~1u;
+            }
+            if (any & valid)
+                park(tile, valid);
+        } else if (__builtin_expect(any != 0ull, 0)) {
+            park(tile, ~0ull);
+        }
+        if ((tile & 31) == 31) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                tally[wave][v][lane] += __popc(bits[v]);
+                bits[v] = 0u;
+            }
+        }
+    };
+
+    if (n_tiles > 0 && (~(dead_rows | full_rows)) != 0u) {
+        MfmaTile t0, t1;
+        float4 a0, b0, a1, b1, a2, b2, a3, b3;
+        load(0, a0, b0);
+        load(1, a1, b1);
+        mfma_first(t0, ops, hi ? a0.y : a0.x, hi ? 1.0f : a0.z, hi ? 1.0f : b0.w);
+        int t = 0;
+        // four tiles per trip so that every buffer index is static: tile t+u uses record buffer u and
+        // accumulator set u & 1; the loads of tile t+u+2 and the MFMAs of tile t+u+1 go out first
+#define SLAM_MFMA_STEP(U, TCUR, RA, RB, TNEXT, NA, NB, LA, LB)                                                      \
+        if (t + U < n_tiles) {                                                                                         \
+            load(t + U + 2, LA, LB);                                                                                   \
+            const unsigned long long any_ =                                                                            \
+                mfma_step(TCUR, TNEXT, ops, hi ? NA.y : NA.x, hi ? 1.0f : NA.z, hi ? 1.0f : NB.w, RA.w, RB.x, RB.y,    \
+                          RB.z, crx, c1, bits, um);                                                                    \
+            finish(t + U, any_);                                                                                       \
+        }
+        for (; t < n_tiles; t += 4) {
+            SLAM_MFMA_STEP(0, t0, a0, b0, t1, a1, b1, a2, b2)
+            SLAM_MFMA_STEP(1, t1, a1, b1, t0, a2, b2, a3, b3)
+            SLAM_MFMA_STEP(2, t0, a2, b2, t1, a3, b3, a0, b0)
+            SLAM_MFMA_STEP(3, t1, a3, b3, t0, a0, b0, a1, b1)
+        }
+#undef SLAM_MFMA_STEP
+    }
+    // ---- counts per (lane, register) -> counts per row -----------------------------------------
+    if (lane < 32)
+        rowcnt[wave][lane] = 0;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        int c = (int)(tally[wave][v][lane] + __popc(bits[v]));
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1)
+            c += __shfl_xor(c, off);
+        if (col == 0)
+            rowcnt[wave][8 * (v >> 2) + (v & 3) + (hi ? 4 : 0)] = c;
+    }
+    if (qn > MFMA_QUEUE)          // more undecided evaluations than the queue holds: fp64 for every live row
+        full_rows = ~dead_rows;
+    // ---- settle the queue: one parked (row, point) per lane and trip ------------------------------
+    for (int q0 = 0; q0 < min(qn, MFMA_QUEUE); q0 += 64) {
+        const int q = q0 + lane;
+        if (q < min(qn, MFMA_QUEUE)) {
+            const unsigned e = queue[wave][q];
+            const int row = (int)(e & 31u), pt = (int)(e >> 5);
+            if (!((full_rows >> row) & 1u)) {
+                const double *ps = a.Rt + ((size_t)set * a.Hs + h_base + row) * 12;
+                double prt[12];
+#pragma unroll
+                for (int c = 0; c < 12; ++c)
+                    prt[c] = ps[c];
+                const double *r = recs64 + (size_t)SCORE_REC * pt;
+                if (supports(prt, a.K, a.tr, r[0], r[1], r[2], r[3], r[4], r[5], r[6], a.thresh))
+                    atomicAdd(&rowcnt[wave][row], 1);
+            }
+        }
+    }
+    // ---- rows the fp32 stage could not take: all points in fp64, lane = point ------------------
+    for (unsigned rows = full_rows; rows != 0u; rows &= rows - 1u) {
+        const int row = __builtin_ctz(rows);
+        const double *ps = a.Rt + ((size_t)set * a.Hs + min(h_base + row, a.H - 1)) * 12;
+        double prt[12];
+#pragma unroll
+        for (int c = 0; c < 12; ++c)
+            prt[c] = ps[c];
+        int c64 = 0;
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            const double *r = recs64 + (size_t)SCORE_REC * min(i, n - 1);
+            const bool s = (i < n) && supports(prt, a.K, a.tr, r[0], r[1], r[2], r[3], r[4], r[5], r[6], a.thresh);
+            c64 += __popcll(__ballot(s));
+        }
+        if (lane == 0)
+            rowcnt[wave][row] = c64;
+    }
+    if (lane < 32 && live)
+        a.counts[(size_t)set * a.Hs + h] = ((dead_rows >> lane) & 1u) ? 0 : rowcnt[wave][lane];
+}
+
 }  // namespace
 }  // namespace slam
 
@@ -678,6 +1004,12 @@ extern "C" int slam_score_hypotheses_range(const double *Rt, int n_sets, int H_t
         if (t_right[1] == 0.0 && t_right[2] == 0.0) {
             if (impl == SLAM_SCORE_F64) {
                 hipLaunchKernelGGL(score_fast_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+            } else if (impl == SLAM_SCORE_MFMA) {
+                // one wavefront per 32 hypotheses, four to a block
+                a.blocks_per_set = (H + 127) / 128;
+                if ((long long)n_sets * a.blocks_per_set > 0x7FFFFFFFLL)
+                    return fail(SLAM_ERR_BAD_ARG, "slam_score_hypotheses: grid too large");
+                hipLaunchKernelGGL(score_mfma_kernel, dim3((unsigned)(n_sets * a.blocks_per_set)), dim3(256), 0, s, a);
             } else if (impl == SLAM_SCORE_SPLIT || (impl != SLAM_SCORE_WIDE && (long long)n_sets * ((H + 63) / 64) < 3072)) {
                 // fewer than three wavefronts per SIMD: split the points of a set over a block
                 a.blocks_per_set = (H + 63) / 64;

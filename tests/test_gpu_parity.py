@@ -23,13 +23,14 @@ def _rand_desc(rng, n, D):
 
 
 # --------------------------------------------------------------------------- knn
-@pytest.fixture(params=["fp4", "valu", "wide"], autouse=True)
+@pytest.fixture(params=["fp4", "valu", "wide", "mfma"], autouse=True)
 def kernel_impl(request):
     """Every test in this file runs against both implementations of the k-NN kernel (fp4 matrix
     cores, VALU popcount) and the forms of the filtered scoring kernel (fp32 first level with the
-    points of a set split over a block or not, fp64 only)."""
+    points of a set split over a block or not, fp64 only, fp32 first level on the matrix cores)."""
     from slam_amd import _lib
-    knn, score = {"fp4": ("fp4", "split"), "valu": ("valu", "f64"), "wide": ("fp4", "wide")}[request.param]
+    knn, score = {"fp4": ("fp4", "split"), "valu": ("valu", "f64"), "wide": ("fp4", "wide"),
+                  "mfma": ("fp4", "mfma")}[request.param]
     _lib.select_kernels(knn, score)
     yield request.param
     _lib.select_kernels("fp4", "auto")

@@ -46,7 +46,7 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 24):
     Rt = pose + (Rt - pose) * 10.0 ** rng.uniform(-6, -1, (H, 1, 1))
     args = (t(Rt), k, tr * scale, t(X), t(Y), t(Z), t(uL32), t(vL32), t(uR32), t(vR32))
     plain = ops.score_hypotheses(*args, thresh=thresh, cap=n, n_host=n, want_masks=False, fast=False)
-    for impl in ("wide", "split", "f64"):
+    for impl in ("wide", "split", "f64", "mfma"):
         _lib.select_kernels(score=impl)
         fast = ops.score_hypotheses(*args, thresh=thresh, cap=n, n_host=n, want_masks=False, fast=True)
         torch.cuda.synchronize()
