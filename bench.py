@@ -219,6 +219,66 @@ def sequence_run(a, rank, world, dev, multi, backend, steps, warmup):
     return dt, info
 
 
+def config0_run(dev, threads):
+    """BASELINE configs[0]: ONE stereo pair at ~1000 keypoints -- left-right matching (k = 1 + row filter,
+    models/Matcher.py:139-145, utils/utils.py:302-315) and triangulation of the kept matches
+    (utils/utils.py:318-335): the C oracle on this host (one thread, all threads) and the GPU, alone (two
+    launches, latency-bound) and as one of 512 such pairs in a batch.  The GPU result is checked against
+    the oracle's."""
+    import torch
+    from oracle import cpu as oracle
+    from slam_amd import pipeline
+    from slam_amd.synthetic import SyntheticSequence, read_cameras
+    k, m1, m2 = read_cameras()
+    Pm, Qm = k @ m1, k @ m2
+    fr = SyntheticSequence(1000, 1).frames[0]
+
+    def cpu_once(th):
+        t0 = time.perf_counter()
+        idx, _ = oracle.hamming_knn(fr.descL, fr.descR, 1, threads=th)
+        keep = oracle.row_filter(idx, fr.kpL[:, 1], fr.kpR[:, 1], 2.0)
+        q = np.flatnonzero(keep)
+        res = oracle.triangulate_dlt(Pm, Qm, fr.kpL[q, 0], fr.kpL[q, 1], fr.kpR[idx[q, 0], 0], fr.kpR[idx[q, 0], 1],
+                                     threads=th)
+        return time.perf_counter() - t0, (idx, q, res)
+
+    cpu1 = min(cpu_once(1)[0] for _ in range(5))
+    cpun = min(cpu_once(threads)[0] for _ in range(5))
+    _, (idx, q, (X, Y, Z, valid)) = cpu_once(1)
+    fe = pipeline.FrontEnd(k, m1, m2)
+
+    def gpu_ms(frames, reps):
+        tb = pipeline.FrameTables.from_frames(frames, dev)
+        ws = fe.prepare(tb, n_hyp=0)
+        fe.run(ws)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fe.run(ws)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps, ws
+
+    one_ms, ws = gpu_ms([fr], 50)
+    smap = ws.smap.cpu().numpy()
+    want = np.full(len(fr.kpL), -1, np.int32)
+    want[q] = idx[q, 0]
+    pts = torch.stack([ws.X, ws.Y, ws.Z], dim=1).cpu().numpy()[q[valid > 0]]
+    ref = np.stack([X, Y, Z], axis=1)[valid > 0]
+    same = bool(np.array_equal(smap, want) and np.array_equal(np.flatnonzero(ws.valid.cpu().numpy()), q[valid > 0])
+                and np.abs(pts - ref).max() <= 1e-9 * np.abs(ref).max())
+    batch_ms, _ = gpu_ms([fr] * 512, 10)
+    return {"workload": "configs[0]: one stereo pair, 1000 keypoints per image, 61-byte descriptors: left-right match "
+                        "(k=1 + 2-pixel row filter) + DLT triangulation of the kept matches",
+            "stereo_matches_kept": int(len(q)), "points_triangulated": int((valid > 0).sum()),
+            "cpu_oracle_ms_1_thread": 1e3 * cpu1, "cpu_oracle_ms_all_threads": 1e3 * cpun, "cpu_threads": threads,
+            "gpu_ms_single_pair": one_ms, "gpu_ms_per_pair_in_a_batch_of_512": batch_ms / 512,
+            "gpu_equals_oracle": same,
+            "note": "the single pair is two kernel launches on an otherwise idle GPU (latency, not throughput); the "
+                    "reference's own cv2 path cannot run here (cv2 is not installed), the C oracle stands in for it"}
+
+
 def stress_run(dev):
     """BASELINE configs[4] on this GPU, beside the headline: one GPU's share of the 8000-keypoint
     sequence (4541 frames over 8 GPUs = 568 frame pairs) through the whole front-end with the
@@ -601,6 +661,14 @@ def main():
         except Exception as exc:                              # never lose the headline over the side measurement
             stress_info = {"error": repr(exc)}
 
+    # ---- BASELINE configs[0] beside the headline: one stereo pair on the CPU oracle and on the GPU
+    config0_info = None
+    if rank == 0 and os.environ.get("SLAM_BENCH_CONFIG0", "1") != "0":
+        try:
+            config0_info = config0_run(dev, min(16, os.cpu_count() or 1))
+        except Exception as exc:                              # never lose the headline over the side measurement
+            config0_info = {"error": repr(exc)}
+
     if rank != 0:
         if multi:
             dist.destroy_process_group()
@@ -731,6 +799,7 @@ def main():
         "stage_rooflines": {"match": match_roof, "score": score_roof, "triangulate": tri_roof},
         "device_ransac": ransac_info,
         "host_fed": ingest_info,
+        "config0": config0_info,
         "full_sequence": full_info,
         "stress": stress_info,
     }
