@@ -126,13 +126,18 @@ struct MatchedArgs {
 
 // A block takes DLT_TILE keypoints of one frame.  Only the kept matches are triangulated (about
 // 60 % of the keypoints): their local indices are compacted into LDS first, so that the
-// wavefronts running the Jacobi iteration are full.
+// wavefronts running the Jacobi iteration are full.  The results go back through LDS as well: the
+// compacted lanes would otherwise store 8 bytes each into scattered rows (partial memory lines:
+// the write traffic measured twice its size); instead the tile's X, Y, Z and flags are written
+// once, row after row, NaN rows of unmatched keypoints included.
 constexpr int DLT_TILE = 512;
 
 __global__ void __launch_bounds__(256) dlt_matched_kernel(const Mat34 P, const Mat34 Q, const MatchedArgs a)
 {
     __shared__ int list[DLT_TILE];
     __shared__ int wave_base[DLT_TILE / 64 + 1];
+    __shared__ double out[3][DLT_TILE];
+    __shared__ uint8_t flag[DLT_TILE];
     const int item = blockIdx.x / a.tiles_per_item;
     const int tile = blockIdx.x - item * a.tiles_per_item;
     const int32_t *seg = a.seg + SLAM_SEG_STRIDE * item;
@@ -141,27 +146,26 @@ __global__ void __launch_bounds__(256) dlt_matched_kernel(const Mat34 P, const M
     if (i0 >= qn)
         return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // pass 1: results of the keypoints without a kept match, and the per-wavefront counts of the others
+    // pass 1: which keypoints have a kept match (per-wavefront counts), NaN / 0 for every row of the tile
     int jj[DLT_TILE / 256];
     unsigned long long mask[DLT_TILE / 256];
+    const double nan = __builtin_nan("");
 #pragma unroll
     for (int e = 0; e < DLT_TILE / 256; ++e) {
-        const int i = i0 + e * 256 + tid;
+        const int l = e * 256 + tid;
+        const int i = i0 + l;
         int j = -1;
         if (i < qn) {
             const size_t g = (size_t)os + i;
             if (a.keep[g])
                 j = a.idx[2 * g];
-            if (j < 0) {
-                const double nan = __builtin_nan("");
-                a.X[g] = nan;
-                a.Y[g] = nan;
-                a.Z[g] = nan;
-                a.valid[g] = 0;
-            }
             if (a.stereo_map)
                 a.stereo_map[g] = j;
         }
+        out[0][l] = nan;
+        out[1][l] = nan;
+        out[2][l] = nan;
+        flag[l] = 0;
         jj[e] = j;
         mask[e] = __ballot(j >= 0);
         if (lane == 0)
@@ -183,23 +187,32 @@ __global__ void __launch_bounds__(256) dlt_matched_kernel(const Mat34 P, const M
     for (int e = 0; e < DLT_TILE / 256; ++e) {
         if (jj[e] >= 0) {
             const int pos = wave_base[e * 4 + wave] + __popcll(mask[e] & ((1ull << lane) - 1ull));
-            list[pos] = e * 256 + tid;
+            list[pos] = (e * 256 + tid) | (jj[e] << 9);       // local keypoint (9 bits) and its right keypoint
         }
     }
     __syncthreads();
     // pass 2: the kept matches, densely
     const int count = wave_base[DLT_TILE / 64];
     for (int k = tid; k < count; k += 256) {
-        const int i = i0 + list[k];
-        const size_t g = (size_t)os + i;
-        const int j = a.idx[2 * g];
+        const int l = list[k] & (DLT_TILE - 1), j = list[k] >> 9;
+        const int i = i0 + l;
         const float fx1 = a.xq[qs + i], fx2 = a.xt[ts + j];
         double x, y, z;
         dlt_point(P, Q, (double)fx1, (double)a.yq[qs + i], (double)fx2, (double)a.yt[ts + j], x, y, z);
-        a.X[g] = x;
-        a.Y[g] = y;
-        a.Z[g] = z;
-        a.valid[g] = !(z <= 0.0 || fx1 < fx2);
+        out[0][l] = x;
+        out[1][l] = y;
+        out[2][l] = z;
+        flag[l] = !(z <= 0.0 || fx1 < fx2);
+    }
+    __syncthreads();
+    // pass 3: the tile's rows, contiguously
+    const int n = min(DLT_TILE, qn - i0);
+    const size_t g0 = (size_t)os + i0;
+    for (int l = tid; l < n; l += 256) {
+        a.X[g0 + l] = out[0][l];
+        a.Y[g0 + l] = out[1][l];
+        a.Z[g0 + l] = out[2][l];
+        a.valid[g0 + l] = flag[l];
     }
 }
 

@@ -23,7 +23,7 @@ from .constants import (LEFT, PIXEL_THRESH, RIGHT, SEED, STEREO_ROW_THRESH, VERT
                         VO_MAX_ITERATIONS)
 from .matcher import Matcher, _default_device
 from .track_database import TrackDatabase
-from .types import keypoints_to_array
+from .types import MatchLists, keypoints_to_array
 
 random.seed(SEED)   # utils/utils.py:13 seeds the global stream at import
 
@@ -70,8 +70,11 @@ def _t(a, dtype):
 # --------------------------------------------------------------------------- matching glue
 def coords_from_kps(matches, kp1, kp2):
     """(x1, y1, x2, y2, indices_mapping[2,M]) of a k=1 match list (utils/utils.py:42-72)."""
-    query_idxs = np.array([match[0].queryIdx for match in matches])
-    train_idxs = np.array([match[0].trainIdx for match in matches])
+    if isinstance(matches, MatchLists) and len(matches) and (matches.train[:, 0] >= 0).all():
+        query_idxs, train_idxs = matches.query.astype(np.int64), matches.train[:, 0].astype(np.int64)
+    else:
+        query_idxs = np.array([match[0].queryIdx for match in matches])
+        train_idxs = np.array([match[0].trainIdx for match in matches])
     indices_mapping = np.stack((query_idxs, train_idxs))
     x1, y1 = np.array([kp1[idx].pt for idx in query_idxs]).T
     x2, y2 = np.array([kp2[idx].pt for idx in train_idxs]).T
@@ -105,7 +108,8 @@ def rectificatied_stereo_pattern(y1, y2, indices_mapping, thresh=1):
 def array_to_dict(arr):
     """{arr[0,i]: arr[1,i]}; later duplicates of a key overwrite earlier ones
     (utils/utils.py:156-175)."""
-    return {arr[0, i]: arr[1, i] for i in range(arr.shape[1])}
+    arr = np.asarray(arr)
+    return dict(zip(arr[0].tolist(), arr[1].tolist()))       # (Python ints: they hash and compare like the numpy scalars)
 
 
 def find_stereo_matches(matcher, file_index):
@@ -170,12 +174,9 @@ def get_3d_points_cloud(inlier_indices_mapping, k, m1, m2, matcher, file_index=0
     xy2 = keypoints_to_array(kp2)[ind2] if len(ind2) else np.zeros((0, 2), np.float32)
     pts, valid = triangulate_points(np.asarray(k, dtype=np.float64), np.asarray(m1, dtype=np.float64),
                                     np.asarray(m2, dtype=np.float64), xy1, xy2)
-    inlier_points_in_3d = []
-    ind_to_3d_point_dict = dict()
-    for n in np.flatnonzero(valid):
-        sol = pts[n]
-        inlier_points_in_3d.append(sol)
-        ind_to_3d_point_dict[ind1[n]] = sol
+    kept = np.flatnonzero(valid)
+    inlier_points_in_3d = list(pts[kept])                    # one [3] array per point, as the reference collects them
+    ind_to_3d_point_dict = dict(zip(ind1[kept].tolist(), inlier_points_in_3d))
     return inlier_points_in_3d, ind_to_3d_point_dict
 
 
@@ -186,6 +187,18 @@ def get_matches_that_appear_in_all_4_images(consecutive_matches, prev_indices_ma
     has a 3-D point, as (prev_left, prev_right, cur_left, cur_right, X) tuples in match
     order (utils/utils.py:338-386).  Dictionary glue, host side like the reference."""
     concensus_matces = []
+    if isinstance(consecutive_matches, MatchLists) and (len(consecutive_matches) == 0 or
+                                                        (consecutive_matches.train[:, 0] >= 0).all()):
+        # the same walk over plain ints; the surviving match lists are made only if someone reads them
+        taken = []
+        for pos, (prev_left_kp, cur_left_kp) in enumerate(zip(consecutive_matches.query.tolist(),
+                                                              consecutive_matches.train[:, 0].tolist())):
+            if (prev_left_kp in prev_indices_mapping and cur_left_kp in cur_indices_mapping
+                    and prev_left_kp in ind_to_3d_point_prev):
+                concensus_matces.append((prev_left_kp, prev_indices_mapping[prev_left_kp], cur_left_kp,
+                                         cur_indices_mapping[cur_left_kp], ind_to_3d_point_prev[prev_left_kp]))
+                taken.append(pos)
+        return concensus_matces, consecutive_matches.subset(taken)
     filtered_matches = []
     for matches_list in consecutive_matches:
         m = matches_list[0]
@@ -224,6 +237,7 @@ class _ScoreSet:
         pad64 = lambda a: _t(np.concatenate([a, np.zeros(cap - self.n)]), np.float64)
         pad32 = lambda a: _t(np.concatenate([a.astype(np.float32), np.zeros(cap - self.n, np.float32)]), np.float32)
         self.cap = cap
+        self._n_dev = None
         self.pts = (pad64(X[:, 0]), pad64(X[:, 1]), pad64(X[:, 2]), pad32(uvL[:, 0]), pad32(uvL[:, 1]),
                     pad32(uvR[:, 0]), pad32(uvR[:, 1]))
 
@@ -233,11 +247,40 @@ class _ScoreSet:
         return cls(X, uvL, uvR, k, m2, thresh)
 
     def counts(self, Rts):
-        """Supporter counts of poses [H,3,4] -> numpy [H]."""
-        Rts = np.ascontiguousarray(Rts, dtype=np.float64).reshape(-1, 3, 4)
-        c = ops.score_hypotheses(_t(Rts, np.float64), self.k, self.tr, *self.pts, thresh=self.thresh, cap=self.cap,
+        """Supporter counts of poses [H,3,4] (numpy or a device tensor [H,12]) -> numpy [H]."""
+        if not torch.is_tensor(Rts):
+            Rts = _t(np.ascontiguousarray(Rts, dtype=np.float64).reshape(-1, 12), np.float64)
+        c = ops.score_hypotheses(Rts.reshape(1, -1, 3, 4), self.k, self.tr, *self.pts, thresh=self.thresh, cap=self.cap,
                                  n_host=self.n)
         return c.cpu().numpy()[0]
+
+    def solve(self, samples):
+        """Minimal solves on the device (slam_p3p_hypotheses: P3P on the first three correspondences of
+        each 4-sample, the fourth disambiguates): samples [H,4] positions -> device tensor [H,12];
+        a failed solve is a NaN pose (the reference's None, utils/utils.py:429-432)."""
+        if self._n_dev is None:
+            self._n_dev = torch.tensor([self.n], dtype=torch.int32, device=self.pts[0].device)
+        smp = torch.from_numpy(np.ascontiguousarray(samples, dtype=np.int32).reshape(1, -1, 4)).to(self._n_dev.device)
+        X, Y, Z, uL, vL = self.pts[:5]
+        return ops.p3p_hypotheses(self.k, X, Y, Z, uL, vL, self.cap, self._n_dev, smp)[0]
+
+    def solve_and_count(self, samples):
+        """(poses numpy [H,3,4] with NaN rows for failed solves, supporter counts numpy [H]) of the
+        minimal samples [H,4]: one solve launch, one scoring launch, two small copies back."""
+        Rt = self.solve(samples)
+        c = ops.score_hypotheses(Rt.reshape(1, -1, 3, 4), self.k, self.tr, *self.pts, thresh=self.thresh, cap=self.cap,
+                                 n_host=self.n)
+        return Rt.cpu().numpy().reshape(-1, 3, 4), c.cpu().numpy()[0]
+
+    def refine(self, Rt):
+        """The tail of ransac_for_pnp on the device (slam_refine_winners): supporters of Rt, Levenberg-
+        Marquardt on their left-image residuals (utils/utils.py:450-454), -> refined pose [3,4] (Rt
+        itself where the reference's `refined_Rt is None` branch applies)."""
+        if self._n_dev is None:
+            self._n_dev = torch.tensor([self.n], dtype=torch.int32, device=self.pts[0].device)
+        Rt0 = _t(np.ascontiguousarray(Rt, dtype=np.float64).reshape(1, 12), np.float64)
+        out, ok, _ = ops.refine_winners(self.k, self.tr, *self.pts, self.cap, self._n_dev, Rt0, thresh=self.thresh)
+        return out.cpu().numpy().reshape(3, 4)
 
     def mask(self, Rt):
         """(float64 0/1 array [n], count) for one pose -- find_supporters' return value."""
@@ -326,16 +369,16 @@ def ransac_on_arrays(X, uvL, uvR, intrinsic_matrix, right_camera_matrix, thresh=
     (sampling range(n) draws the same positions as sampling the list of n tuples), strict
     '>' best update, epsilon / iteration-count update after every scored hypothesis,
     refinement on the winner's supporters, and the quirk that the returned mask and ratio
-    always belong to the refined pose.  Hypotheses are drawn and solved in chunks and
-    scored in ONE GPU call per chunk; the stop rule is then replayed and the random stream
-    rewound to exactly the draws the reference would have made.
+    always belong to the refined pose.  Hypotheses are drawn in chunks; a chunk is solved in ONE
+    GPU call (slam_p3p_hypotheses in place of cv2's AP3P) and scored in one more; the stop rule is
+    then replayed and the random stream rewound to exactly the draws the reference would have made.
+    The refinement (cv2's SOLVEPNP_ITERATIVE in the reference) is slam_refine_winners.
     """
     n_pts = X.shape[0]
     if n_pts < 4:
         print("too small population")
         return None, None, None
     K = np.asarray(intrinsic_matrix, dtype=np.float64)
-    uvL64 = np.asarray(uvL, dtype=np.float64)
     scorer = _ScoreSet(X, uvL, uvR, K, right_camera_matrix, thresh)
     population = range(n_pts)
     best_num_of_supporters = 0
@@ -347,28 +390,23 @@ def ransac_on_arrays(X, uvL, uvR, intrinsic_matrix, right_camera_matrix, thresh=
     while i < I and epsilon != 0:
         chunk = min(chunk_size, I - i)
         chunk_size = min(2 * chunk_size, _RANSAC_CHUNK)
-        states, poses = [], []
+        states, samples = [], []
         for _ in range(chunk):
             states.append(random.getstate())
-            sel = random.sample(population, k=4)
-            try:
-                poses.append(pnp.p3p_4pt(X[sel], uvL64[sel], K))
-            except Exception:
-                poses.append(None)
-        solved = [p for p in poses if p is not None]
-        counts = iter(scorer.counts(np.stack(solved))) if solved else iter(())
+            samples.append(random.sample(population, k=4))
+        poses, counts = scorer.solve_and_count(samples)
+        solved = np.isfinite(poses).all(axis=(1, 2))
         consumed = 0
         for c in range(chunk):
             if not (i < I and epsilon != 0):
                 break
             consumed += 1
-            candidate_Rt = poses[c]
-            if candidate_Rt is None:
+            if not solved[c]:
                 i += 1
                 continue
-            num_good_matches = int(next(counts))
+            num_good_matches = int(counts[c])
             if num_good_matches > best_num_of_supporters:
-                best_Rt_candidate = candidate_Rt
+                best_Rt_candidate = poses[c]
                 best_num_of_supporters = num_good_matches
             epsilon = min(epsilon, 1 - (num_good_matches / n_pts))
             I = min(ransac_num_of_iterations(epsilon, 0.999), max_iterations)
@@ -377,16 +415,7 @@ def ransac_on_arrays(X, uvL, uvR, intrinsic_matrix, right_camera_matrix, thresh=
             random.setstate(states[consumed])   # the reference would not have drawn past the stop
     if best_Rt_candidate is None:
         return None, None, None
-    best_mask, _ = scorer.mask(best_Rt_candidate)
-    sup = np.flatnonzero(best_mask)
-    refined_Rt = None
-    if sup.size >= 3:
-        try:
-            refined_Rt = pnp.refine_pnp(X[sup], uvL64[sup], K, best_Rt_candidate)
-        except Exception:
-            refined_Rt = None
-    if refined_Rt is None:
-        refined_Rt = best_Rt_candidate
+    refined_Rt = scorer.refine(best_Rt_candidate)
     are_supporters_boolean_array, num_good_matches = scorer.mask(refined_Rt)
     if num_good_matches >= best_num_of_supporters:
         best_Rt_candidate = refined_Rt

@@ -18,7 +18,7 @@ import torch
 
 from . import ops
 from .constants import (CONSECUTIVE, FILTERED_MATCHES, FRAMES, HORIZONTAL_REPRESENTATION, LEFT, MATCHES, RIGHT)
-from .types import DMatch, KeyPoint, keypoint_object_array, keypoints_from_array, keypoints_to_array
+from .types import DMatch, KeyPoint, MatchLists, keypoint_object_array, keypoints_from_array, keypoints_to_array
 
 
 def _default_device():
@@ -400,7 +400,10 @@ class Matcher:
 
     def filter_matches(self, indices, file_index):
         """Keep only the matches at the given list positions (models/Matcher.py:162-172)."""
-        self._matches = [self._matches[ind] for ind in indices]
+        if isinstance(self._matches, MatchLists):
+            self._matches = self._matches.subset(indices)
+        else:
+            self._matches = [self._matches[ind] for ind in indices]
         self.cache[file_index][MATCHES] = self._matches
 
     @staticmethod
@@ -413,6 +416,15 @@ class Matcher:
         n = len(matches)
         if n == 0:
             return []
+        if (isinstance(matches, MatchLists) and matches.k == 2 and matches.distance.dtype.kind == "i"
+                and torch.cuda.is_available()):
+            if (matches.train[:, 1] < 0).any():
+                raise ValueError("not enough values to unpack (expected 2, got 1)")      # the reference's `for m, n in`
+            dev = _default_device()
+            keep = ops.ratio_filter(torch.from_numpy(np.ascontiguousarray(matches.train, dtype=np.int32)).to(dev),
+                                    torch.from_numpy(np.ascontiguousarray(matches.distance, dtype=np.int32)).to(dev),
+                                    threshold).cpu().numpy()
+            return matches.subset(np.flatnonzero(keep)).first_neighbours()
         idx = np.empty((n, 2), np.int32)
         dist = np.empty((n, 2), np.int32)
         exact = True
@@ -440,7 +452,7 @@ class Matcher:
             if len(idx) and (idx[:, 1] < 0).any():
                 raise ValueError("not enough values to unpack (expected 2, got 1)")  # the reference's `for m, n in`
             rows = np.flatnonzero(keep)
-            return [[DMatch(i, t, d)] for i, t, d in zip(rows.tolist(), idx[rows, 0].tolist(), dist[rows, 0].tolist())]
+            return MatchLists(rows, idx[rows], dist[rows], 1)
         matches = self.matcher.knnMatch(ref_dsc, oth_dsc, k=2)
         return Matcher.apply_thresholds(matches, thresh)
 
@@ -492,9 +504,5 @@ def _as_object_array(kps):
 
 def _dmatch_lists(idx, dist, k):
     """[n,2] index / distance arrays -> per query a list of up to k DMatch (missing neighbours, index -1,
-    left out).  The arrays go through tolist() first: Python scalars are far cheaper to handle one by
-    one than numpy's."""
-    il, dl = idx.tolist(), dist.tolist()
-    if k == 1:
-        return [[DMatch(i, r[0], d[0])] if r[0] >= 0 else [] for i, (r, d) in enumerate(zip(il, dl))]
-    return [[DMatch(i, r[c], d[c]) for c in range(k) if r[c] >= 0] for i, (r, d) in enumerate(zip(il, dl))]
+    left out): a MatchLists, which makes the lists when they are asked for."""
+    return MatchLists(np.arange(idx.shape[0]), idx, dist, k)

@@ -5,6 +5,9 @@ imgIdx / distance (utils/utils.py:65-66,373-375; models/Matcher.py:155,182,273-2
 and KeyPoint.pt plus the serialised fields (models/Matcher.py:262-270;
 models/TrackDatabase.py:39-43 through Matcher.get_feature_location_frame).
 """
+import operator
+from collections.abc import Sequence
+
 import numpy as np
 
 
@@ -25,13 +28,130 @@ class DMatch:
                 and self.distance == other.distance)
 
 
+class MatchLists(Sequence):
+    """What knnMatch returns -- per query row a list of up to k DMatch, nearest first -- held as
+    the arrays the GPU produced; a row's list (and its DMatch objects) is made the first time it is
+    asked for and kept, so `m[i] is m[i]`.  Behaves as the list of lists the reference's callers
+    index, iterate, slice, len() and random.sample (models/Matcher.py:127-145,154,169-170,181;
+    utils/utils.py:65-66,372-375; utils/plotters.py:634-645); code that has a use for the arrays
+    reads .query / .train / .distance instead of walking the objects.
+
+    query [n] row -> queryIdx; train, distance [n,2] (train < 0: no such neighbour); k = 1 or 2."""
+    __slots__ = ("query", "train", "distance", "k", "_rows")
+
+    def __init__(self, query, train, distance, k):
+        self.query = np.asarray(query)
+        self.train = np.asarray(train).reshape(-1, 2)
+        self.distance = np.asarray(distance).reshape(-1, 2)
+        self.k = int(k)
+        self._rows = None
+
+    def __len__(self):
+        return self.query.shape[0]
+
+    def _make_all(self):
+        """Every row at once: the arrays go through tolist() first (Python scalars are far cheaper to
+        handle one by one than numpy's)."""
+        rows = self._rows
+        if rows is None:
+            rows = self._rows = [None] * len(self)
+        ql, tl, dl = self.query.tolist(), self.train.tolist(), self.distance.tolist()
+        if self.k == 1:
+            for i, row in enumerate(rows):
+                if row is None:
+                    rows[i] = [DMatch(ql[i], tl[i][0], dl[i][0])] if tl[i][0] >= 0 else []
+        else:
+            for i, row in enumerate(rows):
+                if row is None:
+                    rows[i] = [DMatch(ql[i], tl[i][c], dl[i][c]) for c in range(self.k) if tl[i][c] >= 0]
+        return rows
+
+    def __iter__(self):
+        return iter(self._make_all())
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return self._make_all()[i]
+        i = operator.index(i)
+        n = len(self)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError("list index out of range")
+        rows = self._rows
+        if rows is None:
+            rows = self._rows = [None] * n
+        row = rows[i]
+        if row is None:
+            t, d, q = self.train[i], self.distance[i], int(self.query[i])
+            row = rows[i] = [DMatch(q, int(t[c]), d[c].item()) for c in range(self.k) if t[c] >= 0]
+        return row
+
+    def subset(self, positions):
+        """The rows at `positions`, in that order, as another MatchLists (rows already made are shared)."""
+        pos = np.asarray(positions, dtype=np.int64).reshape(-1)
+        out = MatchLists(self.query[pos], self.train[pos], self.distance[pos], self.k)
+        if self._rows is not None:
+            rows = self._rows
+            out._rows = [rows[p] for p in pos.tolist()]
+        return out
+
+    def first_neighbours(self):
+        """MatchLists of the same rows holding only each row's nearest neighbour: the `[m]` lists
+        the ratio test keeps (models/Matcher.py:156,183), sharing the DMatch objects already made."""
+        out = MatchLists(self.query, self.train, self.distance, 1)
+        if self._rows is not None:
+            out._rows = [None if r is None else r[:1] for r in self._rows]
+        return out
+
+    def __eq__(self, other):
+        if isinstance(other, (list, tuple, MatchLists)):
+            return len(self) == len(other) and all(a == b for a, b in zip(self, other))
+        return NotImplemented
+
+    __hash__ = None
+
+    def __reduce__(self):
+        return (list, (list(self),))          # pickles as the plain list of lists it stands for
+
+    def __repr__(self):
+        return f"MatchLists({len(self)} rows, k={self.k})"
+
+
 class KeyPoint:
-    __slots__ = ("pt", "size", "angle", "response", "octave", "class_id")
+    """cv2.KeyPoint's fields.  Only .pt is stored per object; size / angle / response / octave /
+    class_id (read by nothing on this path but the cache serialisation, models/Matcher.py:262-270)
+    live in one optional tuple and otherwise answer with cv2's defaults -- a frame has thousands of
+    keypoints and creating them is what a feature source pays per frame."""
+    __slots__ = ("pt", "_meta")
+    _DEFAULTS = (1.0, -1.0, 0.0, 0, -1)
 
     def __init__(self, x, y, size=1.0, angle=-1.0, response=0.0, octave=0, class_id=-1):
         # cv2.KeyPoint.pt is a tuple of two Python floats holding float32 values
         self.pt = (float(np.float32(x)), float(np.float32(y)))
-        self.size, self.angle, self.response, self.octave, self.class_id = size, angle, response, octave, class_id
+        meta = (size, angle, response, octave, class_id)
+        if meta != KeyPoint._DEFAULTS:
+            self._meta = meta
+
+    def _field(self, i):
+        try:
+            return self._meta[i]
+        except AttributeError:
+            return KeyPoint._DEFAULTS[i]
+
+    size = property(lambda self: self._field(0))
+    angle = property(lambda self: self._field(1))
+    response = property(lambda self: self._field(2))
+    octave = property(lambda self: self._field(3))
+    class_id = property(lambda self: self._field(4))
+
+    def __getstate__(self):
+        return (self.pt, getattr(self, "_meta", None))
+
+    def __setstate__(self, state):
+        self.pt = state[0]
+        if state[1] is not None:
+            self._meta = state[1]
 
     def __repr__(self):
         return f"KeyPoint{self.pt}"
@@ -70,11 +190,9 @@ def keypoints_from_array(xy):
     out = KeyPointList()
     out.array = arr
     new = KeyPoint.__new__
-    for x, y in arr.tolist():
-        kp = new(KeyPoint)
+    out.extend([new(KeyPoint) for _ in range(arr.shape[0])])
+    for kp, x, y in zip(out, arr[:, 0].tolist(), arr[:, 1].tolist()):
         kp.pt = (x, y)
-        kp.size, kp.angle, kp.response, kp.octave, kp.class_id = 1.0, -1.0, 0.0, 0, -1
-        out.append(kp)
     return out
 
 

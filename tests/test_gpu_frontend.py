@@ -109,8 +109,10 @@ def test_temporal_match_join_and_supporters(device, seq):
 
 def _reference_order_ransac(X, uvL, uvR, k, m2, thresh, max_iterations):
     """ransac_for_pnp's loop exactly as written in the reference (one draw, one solve, one
-    score per iteration), with the package's P3P/refine solvers and the C oracle as scorer."""
+    score per iteration), with the package's device P3P / refinement called one pose at a time
+    and the C oracle as scorer."""
     n = X.shape[0]
+    solver = frontend._ScoreSet(X, uvL, uvR, k, m2, thresh)
     tr = m2[:, 3]
     pts = (X[:, 0].copy(), X[:, 1].copy(), X[:, 2].copy(), uvL[:, 0].copy(), uvL[:, 1].copy(), uvR[:, 0].copy(),
            uvR[:, 1].copy())
@@ -119,8 +121,8 @@ def _reference_order_ransac(X, uvL, uvR, k, m2, thresh, max_iterations):
     eps, I, i = 0.99, max_iterations, 0
     while i < I and eps != 0:
         sel = random.sample(range(n), k=4)
-        Rt = pnp.p3p_4pt(X[sel], uvL[sel].astype(np.float64), k)
-        if Rt is None:
+        Rt = solver.solve([sel]).cpu().numpy().reshape(3, 4)
+        if not np.isfinite(Rt).all():            # a failed solve: the reference's None
             i += 1
             continue
         num = int(score(Rt)[0][0])
@@ -132,11 +134,7 @@ def _reference_order_ransac(X, uvL, uvR, k, m2, thresh, max_iterations):
     if best_Rt is None:
         return None, None, None, i
     c, m = score(best_Rt)
-    mask = np.unpackbits(m[0].view(np.uint8), bitorder="little")[:n]
-    sup = np.flatnonzero(mask)
-    refined = pnp.refine_pnp(X[sup], uvL[sup].astype(np.float64), k, best_Rt)
-    if refined is None:
-        refined = best_Rt
+    refined = solver.refine(best_Rt)
     c, m = score(refined)
     mask = np.unpackbits(m[0].view(np.uint8), bitorder="little")[:n].astype(np.float64)
     if int(c[0]) >= best:
