@@ -9,12 +9,12 @@
 # kernel's duration is its own and not that of two kernels sharing the chip; 60 steps so that the
 # first, cold launch of each kernel does not weigh on the average.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-export SLAM_BENCH_STREAMS=1 SLAM_BENCH_RANSAC=0 SLAM_BENCH_INGEST=0 SLAM_BENCH_FULLSEQ=0 SLAM_BENCH_STRESS=0
+export SLAM_BENCH_STREAMS=1 SLAM_BENCH_RANSAC=0 SLAM_BENCH_INGEST=0 SLAM_BENCH_FULLSEQ=0 SLAM_BENCH_STRESS=0 SLAM_BENCH_CONFIG0=0
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" --steps 60 --warmup 3 --no-cpu-baseline > "$OUT/bench_trace.log" 2>&1 || { echo "trace pass failed"; exit 1; }
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench_fetch.log" 2>&1 || { echo "fetch pass failed"; exit 1; }
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench_write.log" 2>&1 || { echo "write pass failed"; exit 1; }
