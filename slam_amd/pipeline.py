@@ -347,8 +347,9 @@ class FrontEnd:
         """PnP-RANSAC of every pair on the device (utils/utils.py:413-464): H minimal samples
         per pair from a generator keyed by (seed, pair, hypothesis), P3P, supporter counts, the
         stopping rule replayed over the counts, refinement of the winner on its supporters,
-        the refined pose's supporters as the inlier tables.  first_slice: hypotheses scored for
-        every pair before the rule is consulted (0: score all at once).  Results: ws.pose [P,12],
+        the refined pose's supporters as the inlier tables.  first_slice: where the stopping rule is
+        consulted -- after that many hypotheses of every pair, then (a tuple) after each further
+        bound for the pairs still running, then after the rest (0: score all at once).  Results: ws.pose [P,12],
         ws.ratio [P], ws.found [P], ws.iters [P], ws.best_count [P], the inlier tables."""
         c = ws.cons
         max_it = ws.H if max_iterations is None else int(max_iterations)
@@ -377,17 +378,18 @@ class FrontEnd:
 
         # The stopping rule usually ends the loop within the first few dozen hypotheses (about
         # 6 at 98 % inliers, about 100 at 50 %): score a first slice for every pair, apply the
-        # rule, and score the rest only for the pairs it has not stopped yet.  The outcome is the
-        # one of scoring everything: the rule never looks past the iteration it stops at.
+        # rule, and go on to the next, larger slice only for the pairs it has not stopped yet.  The
+        # outcome is the one of scoring everything: the rule never looks past the iteration it stops at.
         n_used = min(ws.H, max_it)
-        first = min(int(first_slice), n_used) if first_slice else n_used
-        solve_range(0, first, None)
-        score_range(0, first, None)
-        select(first)
-        if first < n_used:
-            solve_range(first, n_used - first, ws.stopped)
-            score_range(first, n_used - first, ws.stopped)
-            select(n_used)
+        bounds = first_slice if isinstance(first_slice, (tuple, list)) else ((first_slice,) if first_slice else ())
+        bounds = sorted({min(int(b), n_used) for b in bounds if int(b) > 0} | {n_used})
+        done = 0
+        for b in bounds:
+            skip = ws.stopped if done > 0 else None
+            solve_range(done, b - done, skip)
+            score_range(done, b - done, skip)
+            select(b)
+            done = b
         # supporters of the winner, refinement on them and the refined pose's supporter count in
         # one launch; the tables are the refined pose's (the reference reports its mask and ratio
         # whether or not the refined pose is adopted)

@@ -51,6 +51,9 @@ for H in (1000, 10000):
             _p(ws.final_count), _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL), _p(c.vL), _p(c.uR), _p(c.vR), _p(ws.tb.xL), _p(ws.tb.yL),
             _p(ws.tb.xR), _p(ws.inl_rows), _p(ws.inl_loc), _p(ws.n_inl), stream),
         "whole_ransac_one_phase": lambda: fe.ransac(ws, 6, stream, first_slice=0),
+        "whole_ransac_first_32_128": lambda: fe.ransac(ws, 6, stream, first_slice=(32, 128)),
+        "whole_ransac_first_32": lambda: fe.ransac(ws, 6, stream, first_slice=32),
+        "whole_ransac_first_16_64": lambda: fe.ransac(ws, 6, stream, first_slice=(16, 64)),
         "whole_ransac": lambda: fe.ransac(ws, 6, stream),
         "whole_front_end": lambda: fe.run_ransac(ws, 6),
     }
