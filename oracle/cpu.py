@@ -4,8 +4,10 @@ TEST INFRASTRUCTURE ONLY.  Imported by tests/, by __graft_entry__.smoke() and by
 the cpu_baseline leg of bench.py -- always as the checker, never as the thing
 being measured as "the product" and never from the slam_amd package.
 
-Parity status: "parity unpinned" (the reference has no fixtures for this path;
-see the header of slam_oracle.c).
+Parity status: ratio test, row filter, triangulation, join and supporter counts are pinned against
+outputs of the reference's own function bodies (tests/golden/reference_golden.npz,
+tests/test_reference_golden.py); the k-NN scan restates cv2's knnMatch and the minimal-sample
+generator has no counterpart in the reference: "parity unpinned" for those (see slam_oracle.c).
 """
 import ctypes
 import os

@@ -7,7 +7,10 @@ numpy (np.linalg.svd, '@', np.linalg.norm) the same numpy call is made, so for
 triangulation this twin *is* the reference arithmetic (LAPACK gesdd) and pins the
 C/HIP Jacobi solver to the 1e-4 relative contract.
 
-Parity status: "parity unpinned" -- the reference holds no fixtures for this path.
+Parity status: everything here except knn_match is pinned -- held by tests/test_reference_golden.py
+against tests/golden/reference_golden.npz, the outputs of the reference's own function bodies
+executed in the build container (tests/golden/make_reference_golden.py).  knn_match restates
+cv2.BFMatcher.knnMatch from its published behaviour (cv2 is not installed): "parity unpinned".
 """
 import math
 

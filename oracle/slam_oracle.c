@@ -4,13 +4,15 @@
  * check and the cpu_baseline leg of bench.py).  Nothing in the product path may
  * call into this file.
  *
- * PARITY STATUS: "parity unpinned".  The reference ships no tests, fixtures or
- * golden vectors for this path, and its arithmetic for matching lives in
- * OpenCV (opencv-python~=4.7.0.72, requirements.txt:4), which is not installed
- * here.  The functions below restate the reference's own Python
- * (utils/utils.py, models/Matcher.py, models/LoopClosure.py) operation by
- * operation, and OpenCV's published BFMatcher::knnMatch behaviour for the one
- * call that is delegated to it.
+ * PARITY STATUS.  The reference ships no tests, fixtures or golden vectors for this
+ * path.  The functions below restate the reference's own Python (utils/utils.py,
+ * models/Matcher.py, models/LoopClosure.py) operation by operation; ratio test, row
+ * filter, triangulation, join and supporter counts are PINNED: tests/test_reference_golden.py
+ * holds them against tests/golden/reference_golden.npz, the outputs of the reference's own
+ * function bodies executed in the build container (tests/golden/make_reference_golden.py).
+ * "Parity unpinned" remains for oracle_hamming_knn / oracle_l2_knn, which restate OpenCV's
+ * published BFMatcher::knnMatch behaviour (opencv-python~=4.7.0.72, requirements.txt:4, is not
+ * installed here), and for oracle_ransac_sample, which has no counterpart in the reference.
  *
  * Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC (see oracle/Makefile).
  * -ffp-contract=off matters: every fp64 expression here is evaluated with one
