@@ -211,6 +211,8 @@ def sequence_run(a, rank, world, dev, multi, backend, steps, warmup):
         "track_store_equals_host_replay": (bool(np.array_equal(db.get_track_length_data(), host_db.get_track_length_data()))
                                            if host_db is not None else None),
         "host_generate_s": t_gen, "hbm_allocated_GB": torch.cuda.max_memory_allocated() / 1e9,
+        "sampled_pairs_equal_the_oracle": bool(all(_oracle_pair_check(lanes[0][0], tb, seq.frames[s:e + 1], p_, p_, p_ + 1, k, m1, m2,
+                                                                       1.0, 16) for p_ in sorted({0, P // 2, P - 1}) if P > 0)),
         "gather_bytes_per_rank": int(lanes[0][0].layout.nbytes),
         "note": "gpu_ms_per_pass: every stage incl. RANSAC and the gather, inputs resident; track_store_ms: track ids on "
                 "the GPU, copy to the host, array-backed store answering one bundle window's queries; "
@@ -279,6 +281,43 @@ def config0_run(dev, threads):
                     "reference's own cv2 path cannot run here (cv2 is not installed), the C oracle stands in for it"}
 
 
+def _oracle_pair_check(ws, tb, frames, p, fa_i, fb_i, k, m1, m2, ratio, threads):
+    """One pair of a finished run_ransac workspace against the C oracle's own pass (checker, after the timed
+    region): stereo maps of both frames, the pair's 2-NN table and ratio mask, its consensus rows, the supporter
+    counts of the first 128 device-made hypotheses.  True iff everything is identical."""
+    from oracle import cpu as oracle
+    Pm, Qm = k @ m1, k @ m2
+
+    def stereo(fr):
+        idx, _ = oracle.hamming_knn(fr.descL, fr.descR, 1, threads=threads)
+        keep = oracle.row_filter(idx, fr.kpL[:, 1], fr.kpR[:, 1], 2.0)
+        j = np.where(keep > 0, idx[:, 0], 0)
+        X, Y, Z, valid = oracle.triangulate_dlt(Pm, Qm, fr.kpL[:, 0], fr.kpL[:, 1], fr.kpR[j, 0], fr.kpR[j, 1], threads=threads)
+        return np.where(keep > 0, idx[:, 0], -1).astype(np.int32), (valid * (keep > 0)).astype(np.uint8), X, Y, Z
+
+    fa, fb = frames[fa_i], frames[fb_i]
+    sa, sb = stereo(fa), stereo(fb)
+    la, lb = slice(int(tb.offL[fa_i]), int(tb.offL[fa_i + 1])), slice(int(tb.offL[fb_i]), int(tb.offL[fb_i + 1]))
+    smap = ws.smap.cpu().numpy()
+    ok = np.array_equal(smap[la], sa[0]) and np.array_equal(smap[lb], sb[0])
+    ok = ok and np.array_equal(ws.valid.cpu().numpy()[la], sa[1])
+    tidx, tdist = oracle.hamming_knn(fa.descL, fb.descL, 2, threads=threads)
+    tkeep = oracle.ratio_filter(tidx, tdist, ratio)
+    ts = slice(int(ws.t_off[p]), int(ws.t_off[p]) + len(fa.descL))
+    ok = ok and np.array_equal(ws.t_idx.cpu().numpy()[ts], tidx) and np.array_equal(ws.t_keep.cpu().numpy()[ts], tkeep)
+    rows = oracle.join(tidx, tkeep, sa[0], sa[1], sb[0])
+    n = int(ws.cons.count[p].item())
+    ok = ok and n == len(rows) and np.array_equal(ws.cons.rows.cpu().numpy()[p * ws.cap:p * ws.cap + n], rows)
+    if ok and n >= 4:
+        first = min(128, ws.H)
+        with np.errstate(all="ignore"):
+            rc = oracle.score_hypotheses(ws.Rt_gen[p, :first].cpu().numpy(), k, m2[:, 3], sa[2][rows[:, 0]], sa[3][rows[:, 0]],
+                                         sa[4][rows[:, 0]], fb.kpL[rows[:, 2], 0], fb.kpL[rows[:, 2], 1],
+                                         fb.kpR[rows[:, 3], 0], fb.kpR[rows[:, 3], 1], 2.0, threads=threads)
+        ok = np.array_equal(ws.counts[p, :first].cpu().numpy(), rc)
+    return bool(ok)
+
+
 def stress_run(dev):
     """BASELINE configs[4] on this GPU, beside the headline: one GPU's share of the 8000-keypoint
     sequence (4541 frames over 8 GPUs = 568 frame pairs) through the whole front-end with the
@@ -324,6 +363,8 @@ def stress_run(dev):
         "mean_consensus_per_pair": float(ws.cons.count[:P].float().mean().item()),
         "mean_inlier_ratio": float(ws.ratio[:P].mean().item()),
         "pose_error_vs_truth_max": float(np.abs(ws.pose.cpu().numpy()[:P].reshape(P, 3, 4) - truth).max()),
+        "first_and_last_pair_equal_the_oracle": bool(all(_oracle_pair_check(ws, tb, seq.frames, p, p, p + 1, k, m1, m2, 1.0, 16)
+                                                         for p in (0, P - 1))),
         "host_generate_s": t_gen, "hbm_allocated_GB": torch.cuda.max_memory_allocated() / 1e9}
     del ws, tb, seq
     torch.cuda.empty_cache()
@@ -352,6 +393,8 @@ def stress_run(dev):
         "s_per_sweep": dt, "keyframe_pairs_per_s": P / dt, "descriptor_pairs_per_s": desc_pairs / dt,
         "pairs_with_10_consensus_and_a_pose": int((found & (n_cons >= 10)).sum()),
         "mean_consensus": float(n_cons.mean()), "host_generate_s": t_gen,
+        "sampled_pairs_equal_the_oracle": bool(all(_oracle_pair_check(ws, tb, seq.frames, p, int(pairs[p, 0]), int(pairs[p, 1]),
+                                                                       k, m1, m2, 0.6, 16) for p in (0, P // 2, P - 1))),
         "hbm_allocated_GB": torch.cuda.max_memory_allocated() / 1e9}
     del ws, tb, seq
     torch.cuda.empty_cache()
