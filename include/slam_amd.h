@@ -523,6 +523,23 @@ int slam_refine_winners(const double *K_host, const double *t_right_host, double
                         void *stream);
 
 /*
+ * slam_refine_winners with the right image's residuals of the same points added to the
+ * cost (the right camera sits at t_right from the left one).  No counterpart in the
+ * reference, whose refinement sees the left keypoints only (utils/utils.py:452): an
+ * option for callers that chain thousands of poses, where the left-only cost on
+ * triangulated points leaves a heading bias of constant sign.  Same arguments, same
+ * supporter test, same ok / ref_count meaning.
+ */
+int slam_refine_winners_stereo(const double *K_host, const double *t_right_host, double thresh,
+                               const double *X_dev, const double *Y_dev, const double *Z_dev,
+                               const float *uL_dev, const float *vL_dev,
+                               const float *uR_dev, const float *vR_dev,
+                               int cap, const int32_t *n_dev, int n_host,
+                               const double *Rt0_dev, int n_sets, int iterations,
+                               double *Rt_out_dev, int32_t *ok_dev, int32_t *ref_count_dev,
+                               void *stream);
+
+/*
  * Final choice (utils/utils.py:455-463): out_Rt = refined pose when its supporter count
  * is >= the winner's, else the winner; ratio = refined count / n (always the refined
  * pose's, as in the reference); found = 0 (and NaNs) where the set had fewer than 4

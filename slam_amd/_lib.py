@@ -39,6 +39,7 @@ EXPORTS = (
     "slam_ransac_select",
     "slam_refine_poses",
     "slam_refine_winners",
+    "slam_refine_winners_stereo",
     "slam_ransac_adopt",
 )
 
@@ -121,6 +122,8 @@ def load():
     lib.slam_refine_poses.argtypes = [vp] * 6 + [ci, vp, ci, vp, ci, vp, ci, ci, vp, vp, vp]
     lib.slam_refine_winners.restype = ci
     lib.slam_refine_winners.argtypes = [vp, vp, cd] + [vp] * 7 + [ci, vp, ci, vp, ci, ci, vp, vp, vp, vp]
+    lib.slam_refine_winners_stereo.restype = ci
+    lib.slam_refine_winners_stereo.argtypes = lib.slam_refine_winners.argtypes
     lib.slam_ransac_adopt.restype = ci
     lib.slam_ransac_adopt.argtypes = [ci, vp, ci, ci] + [vp] * 8
     _lib = lib

@@ -537,8 +537,12 @@ __device__ __forceinline__ bool solve6(double (&M)[6][6], double (&rhs)[6], doub
 // One block per point set; every iteration is one block-wide reduction of NSUM sums.  Thread t
 // owns points t, t+256, ...: the first REFINE_JREG of them stay in registers for all iterations
 // (an iteration then touches no memory but LDS), later ones are re-read.
+// STEREO adds the right image's residuals of the same points (camera offset a.tr, keypoints
+// uR/vR) to the cost: not what the reference minimises, an option for callers who want the
+// pose without the heading bias of the left-only cost.
 constexpr int REFINE_JREG = 6;
 
+template <bool STEREO>
 __global__ void __launch_bounds__(256, 2) refine_kernel(const RefineArgs a)
 {
     __shared__ double part[4][NSUM];
@@ -604,16 +608,15 @@ __global__ void __launch_bounds__(256, 2) refine_kernel(const RefineArgs a)
 #pragma unroll
         for (int k = 0; k < 12; ++k)
             R[k] = cand[k];
-        auto add_point = [&](double X, double Y, double Z, float u, float v) {
-            const double y0 = R[0] * X + R[1] * Y + R[2] * Z + R[3];
-            const double y1 = R[4] * X + R[5] * Y + R[6] * Z + R[7];
-            const double y2 = R[8] * X + R[9] * Y + R[10] * Z + R[11];
-            const double iz = 1.0 / y2;
-            const double r0 = a.fx * y0 * iz + a.cx - (double)u;
-            const double r1 = a.fy * y1 * iz + a.cy - (double)v;
-            // d(proj)/dY rows and the two Jacobian rows over (rotation, translation)
-            const double du0 = a.fx * iz, du2 = -a.fx * y0 * iz * iz;
-            const double dv1 = a.fy * iz, dv2 = -a.fy * y1 * iz * iz;
+        // one camera's two residual rows for the point y (left frame), seen from a camera at
+        // offset o: the projection of z = y + o; d z / d(pose) = d y / d(pose) = [-[y]x | I]
+        auto add_cam = [&](double y0, double y1, double y2, double o0, double o1, double o2, double u, double v) {
+            const double z0 = y0 + o0, z1 = y1 + o1, z2 = y2 + o2;
+            const double iz = 1.0 / z2;
+            const double r0 = a.fx * z0 * iz + a.cx - u;
+            const double r1 = a.fy * z1 * iz + a.cy - v;
+            const double du0 = a.fx * iz, du2 = -a.fx * z0 * iz * iz;
+            const double dv1 = a.fy * iz, dv2 = -a.fy * z1 * iz * iz;
             const double Ju[6] = {-(-du2 * y1), -(-du0 * y2 + du2 * y0), -(du0 * y1), du0, 0.0, du2};
             const double Jv[6] = {-(dv1 * y2 - dv2 * y1), -(dv2 * y0), -(-dv1 * y0), 0.0, dv1, dv2};
             int k = 0;
@@ -627,16 +630,24 @@ __global__ void __launch_bounds__(256, 2) refine_kernel(const RefineArgs a)
                 acc[21 + p] += Ju[p] * r0 + Jv[p] * r1;
             acc[27] += r0 * r0 + r1 * r1;
         };
+        auto add_point = [&](int i, double X, double Y, double Z, float u, float v) {
+            const double y0 = R[0] * X + R[1] * Y + R[2] * Z + R[3];
+            const double y1 = R[4] * X + R[5] * Y + R[6] * Z + R[7];
+            const double y2 = R[8] * X + R[9] * Y + R[10] * Z + R[11];
+            add_cam(y0, y1, y2, 0.0, 0.0, 0.0, (double)u, (double)v);
+            if constexpr (STEREO)
+                add_cam(y0, y1, y2, a.tr.v[0], a.tr.v[1], a.tr.v[2], (double)a.uR[pbase + i], (double)a.vR[pbase + i]);
+        };
 #pragma unroll
         for (int j = 0; j < REFINE_JREG; ++j)
             if ((reg_in >> j) & 1u)
-                add_point(pX[j], pY[j], pZ[j], pu[j], pv[j]);
+                add_point(tid + 256 * j, pX[j], pY[j], pZ[j], pu[j], pv[j]);
         for (int j = REFINE_JREG, i = tid + 256 * REFINE_JREG; i < n; ++j, i += 256) {
             const double X = a.X[pbase + i], Y = a.Y[pbase + i], Z = a.Z[pbase + i];
             const float u = a.uL[pbase + i], v = a.vL[pbase + i];
             const bool in = j - REFINE_JREG < 64 ? (later_in >> (j - REFINE_JREG)) & 1ull : starts_in(i, X, Y, Z, u, v);
             if (in)
-                add_point(X, Y, Z, u, v);
+                add_point(i, X, Y, Z, u, v);
         }
         // 16-lane rows first, through the lane-permuting operand path of the vector ALU (four
         // steps, no LDS round trip), then the 16 row sums of the block through LDS
@@ -929,7 +940,8 @@ namespace {
 int launch_refine(const char *who, const double *K, const double *t_right, double thresh, const double *X,
                   const double *Y, const double *Z, const float *uL, const float *vL, const float *uR, const float *vR,
                   int cap, const int32_t *n_dev, int n_host, const uint64_t *masks, int mask_words, const double *Rt0,
-                  int n_sets, int iterations, double *Rt_out, int32_t *ok, int32_t *ref_count, void *stream)
+                  int n_sets, int iterations, double *Rt_out, int32_t *ok, int32_t *ref_count, bool stereo,
+                  void *stream)
 {
     if (n_sets < 0 || cap < 0 || iterations < 0)
         return fail(SLAM_ERR_BAD_ARG, "%s: negative size", who);
@@ -968,7 +980,10 @@ int launch_refine(const char *who, const double *K, const double *t_right, doubl
     a.ok = ok;
     a.ref_count = ref_count;
     a.iterations = iterations;
-    hipLaunchKernelGGL(refine_kernel, dim3(n_sets), dim3(256), 0, (hipStream_t)stream, a);
+    if (stereo)
+        hipLaunchKernelGGL(refine_kernel<true>, dim3(n_sets), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(refine_kernel<false>, dim3(n_sets), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch(who);
 }
 }  // namespace
@@ -983,7 +998,7 @@ extern "C" int slam_refine_poses(const double *K, const double *X, const double 
     if (n_sets > 0 && cap >= 0 && mask_words < (cap + 63) / 64)
         return fail(SLAM_ERR_BAD_ARG, "slam_refine_poses: mask_words %d < ceil(cap/64)", mask_words);
     return launch_refine("slam_refine_poses", K, nullptr, 0.0, X, Y, Z, uL, vL, nullptr, nullptr, cap, n_dev, n_host,
-                         masks, mask_words, Rt0, n_sets, iterations, Rt_out, ok, nullptr, stream);
+                         masks, mask_words, Rt0, n_sets, iterations, Rt_out, ok, nullptr, false, stream);
 }
 
 extern "C" int slam_refine_winners(const double *K, const double *t_right, double thresh, const double *X,
@@ -995,7 +1010,19 @@ extern "C" int slam_refine_winners(const double *K, const double *t_right, doubl
     if (n_sets > 0 && (!t_right || !ref_count || (cap > 0 && (!uR || !vR))))
         return fail(SLAM_ERR_BAD_ARG, "slam_refine_winners: null buffer");
     return launch_refine("slam_refine_winners", K, t_right, thresh, X, Y, Z, uL, vL, uR, vR, cap, n_dev, n_host, nullptr,
-                         0, Rt0, n_sets, iterations, Rt_out, ok, ref_count, stream);
+                         0, Rt0, n_sets, iterations, Rt_out, ok, ref_count, false, stream);
+}
+
+extern "C" int slam_refine_winners_stereo(const double *K, const double *t_right, double thresh, const double *X,
+                                          const double *Y, const double *Z, const float *uL, const float *vL,
+                                          const float *uR, const float *vR, int cap, const int32_t *n_dev, int n_host,
+                                          const double *Rt0, int n_sets, int iterations, double *Rt_out, int32_t *ok,
+                                          int32_t *ref_count, void *stream)
+{
+    if (n_sets > 0 && (!t_right || !ref_count || (cap > 0 && (!uR || !vR))))
+        return fail(SLAM_ERR_BAD_ARG, "slam_refine_winners_stereo: null buffer");
+    return launch_refine("slam_refine_winners_stereo", K, t_right, thresh, X, Y, Z, uL, vL, uR, vR, cap, n_dev, n_host,
+                         nullptr, 0, Rt0, n_sets, iterations, Rt_out, ok, ref_count, true, stream);
 }
 
 extern "C" int slam_ransac_adopt(int n_sets, const int32_t *n_dev, int n_host, int cap, const int32_t *best_count,

@@ -408,10 +408,13 @@ def refine_poses(K, X, Y, Z, uL, vL, cap, n_dev, masks, Rt0, iterations=30):
     return out[:n_sets], ok[:n_sets]
 
 
-def refine_winners(K, t_right, X, Y, Z, uL, vL, uR, vR, cap, n_dev, Rt0, thresh=2.0, iterations=30):
+def refine_winners(K, t_right, X, Y, Z, uL, vL, uR, vR, cap, n_dev, Rt0, thresh=2.0, iterations=30, stereo=False):
     """(Rt [n_sets,12], ok [n_sets], ref_count [n_sets]): the supporters of Rt0 found on the
-    device, the refinement on them, and the supporter count of the result (slam_refine_winners)."""
+    device, the refinement on them, and the supporter count of the result (slam_refine_winners).
+    stereo=True adds the right image's residuals to the refinement cost
+    (slam_refine_winners_stereo; the reference minimises the left image's alone)."""
     lib = _lib.load()
+    entry = lib.slam_refine_winners_stereo if stereo else lib.slam_refine_winners
     n_sets = Rt0.shape[0]
     Kh, Kp = _host_f64(K, 9, "K")
     th, tp = _host_f64(t_right, 3, "t_right")
@@ -419,14 +422,12 @@ def refine_winners(K, t_right, X, Y, Z, uL, vL, uR, vR, cap, n_dev, Rt0, thresh=
     out = torch.empty((max(n_sets, 1), 12), dtype=torch.float64, device=dev)
     ok = torch.zeros(max(n_sets, 1), dtype=torch.int32, device=dev)
     ref_count = torch.zeros(max(n_sets, 1), dtype=torch.int32, device=dev)
-    st = lib.slam_refine_winners(Kp, tp, float(thresh), _dev(X, torch.float64, "X"), _dev(Y, torch.float64, "Y"),
-                                 _dev(Z, torch.float64, "Z"), _dev(uL, torch.float32, "uL"),
-                                 _dev(vL, torch.float32, "vL"), _dev(uR, torch.float32, "uR"),
-                                 _dev(vR, torch.float32, "vR"), int(cap), _dev(n_dev, torch.int32, "n_dev"), 0,
-                                 _dev(Rt0, torch.float64, "Rt0"), n_sets, int(iterations),
-                                 ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ok.data_ptr()),
-                                 ctypes.c_void_p(ref_count.data_ptr()), _stream())
-    _lib.check(st, "slam_refine_winners")
+    st = entry(Kp, tp, float(thresh), _dev(X, torch.float64, "X"), _dev(Y, torch.float64, "Y"),
+               _dev(Z, torch.float64, "Z"), _dev(uL, torch.float32, "uL"), _dev(vL, torch.float32, "vL"),
+               _dev(uR, torch.float32, "uR"), _dev(vR, torch.float32, "vR"), int(cap), _dev(n_dev, torch.int32, "n_dev"), 0,
+               _dev(Rt0, torch.float64, "Rt0"), n_sets, int(iterations), ctypes.c_void_p(out.data_ptr()),
+               ctypes.c_void_p(ok.data_ptr()), ctypes.c_void_p(ref_count.data_ptr()), _stream())
+    _lib.check(st, "slam_refine_winners_stereo" if stereo else "slam_refine_winners")
     return out[:n_sets], ok[:n_sets], ref_count[:n_sets]
 
 

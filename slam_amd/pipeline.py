@@ -343,13 +343,15 @@ class FrontEnd:
                                                _p(ws.n_inl), stream)
         _lib.check(st, "slam_build_inlier_tables")
 
-    def ransac(self, ws, seed, stream, max_iterations=None, refine_iterations=30, first_slice=128):
+    def ransac(self, ws, seed, stream, max_iterations=None, refine_iterations=30, first_slice=128, stereo_refine=False):
         """PnP-RANSAC of every pair on the device (utils/utils.py:413-464): H minimal samples
         per pair from a generator keyed by (seed, pair, hypothesis), P3P, supporter counts, the
         stopping rule replayed over the counts, refinement of the winner on its supporters,
         the refined pose's supporters as the inlier tables.  first_slice: where the stopping rule is
         consulted -- after that many hypotheses of every pair, then (a tuple) after each further
-        bound for the pairs still running, then after the rest (0: score all at once).  Results: ws.pose [P,12],
+        bound for the pairs still running, then after the rest (0: score all at once).  stereo_refine:
+        the refinement also minimises the right image's residuals (not the reference's cost, which is
+        the left image's alone at utils/utils.py:452; it removes that cost's heading bias).  Results: ws.pose [P,12],
         ws.ratio [P], ws.found [P], ws.iters [P], ws.best_count [P], the inlier tables."""
         c = ws.cons
         max_it = ws.H if max_iterations is None else int(max_iterations)
@@ -393,10 +395,10 @@ class FrontEnd:
         # supporters of the winner, refinement on them and the refined pose's supporter count in
         # one launch; the tables are the refined pose's (the reference reports its mask and ratio
         # whether or not the refined pose is adopted)
-        _lib.check(lib.slam_refine_winners(ws.hK, ws.hT, self.pix_thresh, _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL), _p(c.vL),
-                                           _p(c.uR), _p(c.vR), ws.cap, _p(c.count), 0, _p(ws.best_Rt), ws.P,
-                                           int(refine_iterations), _p(ws.ref_Rt), _p(ws.ref_ok), _p(ws.final_count),
-                                           stream), "slam_refine_winners")
+        refine = lib.slam_refine_winners_stereo if stereo_refine else lib.slam_refine_winners
+        _lib.check(refine(ws.hK, ws.hT, self.pix_thresh, _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL), _p(c.vL), _p(c.uR), _p(c.vR),
+                          ws.cap, _p(c.count), 0, _p(ws.best_Rt), ws.P, int(refine_iterations), _p(ws.ref_Rt),
+                          _p(ws.ref_ok), _p(ws.final_count), stream), "slam_refine_winners")
         _lib.check(lib.slam_ransac_adopt(ws.P, _p(c.count), 0, ws.cap, _p(ws.best_count), _p(ws.final_count),
                                          _p(ws.best_Rt), _p(ws.ref_Rt), _p(ws.pose), _p(ws.ratio), _p(ws.found),
                                          stream), "slam_ransac_adopt")
@@ -406,7 +408,7 @@ class FrontEnd:
                                           _p(c.uL), _p(c.vL), _p(c.uR), _p(c.vR), _p(tb.xL), _p(tb.yL), _p(tb.xR),
                                           _p(ws.inl_rows), _p(ws.inl_loc), _p(ws.n_inl), stream), "slam_winner_tables")
 
-    def run_ransac(self, ws, seed, max_iterations=None, first_slice=128):
+    def run_ransac(self, ws, seed, max_iterations=None, first_slice=128, stereo_refine=False):
         """Stages 1-4 followed by the device-side RANSAC, all on the current stream."""
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         if ws.F == 0:
@@ -418,7 +420,8 @@ class FrontEnd:
         if ws.P > 0:
             self.temporal_match(ws, stream)
             self.join(ws, stream)
-            self.ransac(ws, seed, stream, max_iterations=max_iterations, first_slice=first_slice)
+            self.ransac(ws, seed, stream, max_iterations=max_iterations, first_slice=first_slice,
+                        stereo_refine=stereo_refine)
         return ws
 
     def run(self, ws, Rt=None):

@@ -60,20 +60,24 @@ def track_camera_batched(frames, cameras=None, thresh=1, max_iterations=VO_MAX_I
     return cam, db
 
 
-def track_camera_device(frames, seed=6, n_hyp=VO_MAX_ITERATIONS, cameras=None, thresh=1, device=None):
+def track_camera_device(frames, seed=6, n_hyp=VO_MAX_ITERATIONS, cameras=None, thresh=1, device=None,
+                        stereo_refine=False):
     """(camera_positions [F,3], TrackDatabase) with the whole RANSAC on the device as well:
     per pair `n_hyp` minimal samples from a generator keyed by (seed, pair, hypothesis), P3P,
     supporter counts, the reference's stopping rule, refinement of the winner, inlier tables
     (pipeline.FrontEnd.run_ransac).  The track store is an ArrayTrackDatabase built from device-made track ids.  The
     draws differ from the reference's process-global `random` stream, which chains the frames
-    one after the other; everything downstream of the draws follows utils/utils.py:413-464."""
+    one after the other; everything downstream of the draws follows utils/utils.py:413-464.
+    stereo_refine=True departs from the reference on purpose: the winner is refined on the left AND
+    right residuals (slam_refine_winners_stereo), which removes the heading bias the left-only cost
+    of utils/utils.py:452 leaves on triangulated points."""
     k, m1, m2 = cameras if cameras is not None else frontend.read_cameras()
     if device is None:
         device = frontend._default_device()
     fe = pipeline.FrontEnd(k, m1, m2, row_thresh=STEREO_ROW_THRESH, ratio_thresh=thresh, pix_thresh=PIXEL_THRESH)
     tb = pipeline.FrameTables.from_frames(frames, device)
     ws = fe.prepare(tb, n_hyp=n_hyp)
-    fe.run_ransac(ws, seed)
+    fe.run_ransac(ws, seed, stereo_refine=stereo_refine)
     torch.cuda.synchronize()
     found = ws.found.cpu().numpy()[:ws.P]
     assert found.all(), f"RANSAC Couldn't find a transformation from frame {int(np.argmin(found))} to the next one"

@@ -44,7 +44,9 @@ def test_drift_is_a_yaw_bias_of_the_left_image_pnp_on_triangulated_points(device
     host = summarize("host", rel, gt, m1, seq.step)
     both = summarize("host, left+right residuals", rel_lr, gt, m1, seq.step)
     true3d = summarize("host, true 3-D points", rel_gtx, gt, m1, seq.step)
-    for r in (dev, host, both, true3d):
+    dev_both = summarize("device, left+right residuals", device_run(seq, k, m1, m2, stereo_refine=True)[0], gt, m1,
+                         seq.step)
+    for r in (dev, host, both, true3d, dev_both):
         print({key: r[key] for key in ("name", "rot_bias_rad", "rot_sem_rad", "t_bias_m", "end_point_drift_m")})
     yaw = lambda r: (r["rot_bias_rad"][1], r["rot_sem_rad"][1])
     # (a) the two solvers show the same bias, and every single pose is close to the truth
@@ -59,7 +61,8 @@ def test_drift_is_a_yaw_bias_of_the_left_image_pnp_on_triangulated_points(device
         assert r["max_drift_m"] < 2 * (r["predicted_from_yaw_bias_m"] + r["predicted_from_yaw_walk_m"]
                                        + r["predicted_from_translation_bias_m"])
     # (c) not the solver but the cost: with the right image's residuals too, or with the true 3-D points, it is gone
-    for r in (both, true3d):
+    # (the device's own stereo refinement, slam_refine_winners_stereo, is that option on the batched path)
+    for r in (both, true3d, dev_both):
         b, s = yaw(r)
         assert abs(b) < 4 * s + 1e-6
         assert r["max_drift_m"] < 0.5 * dev["max_drift_m"]

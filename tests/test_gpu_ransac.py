@@ -210,6 +210,60 @@ def test_fused_refinement_matches_the_three_launch_route(device):
     assert (got[:5] >= c0.reshape(-1).cpu().numpy()[:5] - 5).all()        # refinement keeps (about) every supporter
 
 
+def test_stereo_refinement_matches_the_host_solver(device):
+    """slam_refine_winners_stereo (left + right residuals, an option the reference does not have)
+    against pnp.refine_pnp with the right image's keypoints on the same supporters: same pose to
+    solver tolerance, ref_count = the supporters of the pose returned.  Set sizes on both sides of
+    what a thread keeps in registers."""
+    k, m1, m2 = read_cameras()
+    t_right = m2[:, 3]
+    rng = np.random.default_rng(23)
+    sizes = [300, 1536, 1537, 5000, 0, 2]
+    cap = max(sizes)
+    S = len(sizes)
+    X = np.zeros((S, cap, 3))
+    uvL = np.zeros((S, cap, 2), np.float32)
+    uvR = np.zeros((S, cap, 2), np.float32)
+    start = np.zeros((S, 12))
+    truth = []
+    for s, n in enumerate(sizes):
+        Xs, uv, pose = _scene(rng, max(n, 1), k, noise=0.4)
+        Ys = Xs @ pose[:, :3].T + pose[:, 3]
+        uR = (k[0, 0] * (Ys[:, 0] + t_right[0]) / Ys[:, 2] + k[0, 2] + rng.normal(0, 0.4, len(Ys))).astype(np.float32)
+        vR = (k[1, 1] * Ys[:, 1] / Ys[:, 2] + k[1, 2] + rng.normal(0, 0.4, len(Ys))).astype(np.float32)
+        bad = rng.random(len(Ys)) < 0.25
+        uv[bad] += rng.normal(0, 30, (int(bad.sum()), 2)).astype(np.float32)
+        X[s, :n], uvL[s, :n], uvR[s, :n, 0], uvR[s, :n, 1] = Xs[:n], uv[:n], uR[:n], vR[:n]
+        st = pose.copy()
+        st[:, :3] = rodrigues(rng.normal(0, 4e-4, 3)) @ st[:, :3]
+        st[:, 3] += rng.normal(0, 0.004, 3)
+        start[s] = st.reshape(12)
+        truth.append(pose)
+    n_dev = _t(np.array(sizes, np.int32), device)
+    pts = [_t(a.reshape(-1), device) for a in (X[..., 0], X[..., 1], X[..., 2], uvL[..., 0], uvL[..., 1], uvR[..., 0],
+                                                uvR[..., 1])]
+    Rt0 = _t(start, device)
+    _, m0 = ops.score_hypotheses(Rt0.reshape(S, 1, 3, 4), k, t_right, *pts, thresh=2.0, cap=cap, n_dev=n_dev,
+                                 want_masks=True)
+    m0 = m0.reshape(S, -1).cpu().numpy().view(np.uint64)
+    Rt_s, ok_s, c_s = ops.refine_winners(k, t_right, *pts, cap, n_dev, Rt0, thresh=2.0, stereo=True)
+    Rt_l, ok_l, c_l = ops.refine_winners(k, t_right, *pts, cap, n_dev, Rt0, thresh=2.0)
+    c_check = ops.score_hypotheses(Rt_s.reshape(S, 1, 3, 4), k, t_right, *pts, thresh=2.0, cap=cap, n_dev=n_dev, fast=False)
+    assert torch.equal(c_check.reshape(-1), c_s)
+    assert ok_s.cpu().tolist() == [1, 1, 1, 1, 0, 0] and ok_l.cpu().tolist() == ok_s.cpu().tolist()
+    got, left = Rt_s.cpu().numpy().reshape(S, 3, 4), Rt_l.cpu().numpy().reshape(S, 3, 4)
+    for s, n in enumerate(sizes[:4]):
+        sup = np.array([(int(m0[s, i >> 6]) >> (i & 63)) & 1 for i in range(n)], dtype=bool)
+        want = pnp.refine_pnp(X[s, :n][sup], uvL[s, :n][sup].astype(np.float64), k, start[s].reshape(3, 4),
+                              points_2d_right=uvR[s, :n][sup].astype(np.float64), t_right=t_right)
+        assert np.abs(got[s] - want).max() < 1e-7, s
+        assert np.abs(got[s][:, :3] @ got[s][:, :3].T - np.eye(3)).max() < 1e-12
+        assert np.abs(got[s] - truth[s]).max() < 5e-3
+        assert np.abs(got[s] - left[s]).max() > 1e-9            # a different cost, a (slightly) different optimum
+    # fewer than three supporters, or none: the start pose comes back
+    assert np.array_equal(got[4].reshape(12), start[4]) and np.array_equal(got[5].reshape(12), start[5])
+
+
 def test_device_ransac_end_to_end(device):
     k, m1, m2 = read_cameras()
     seq = SyntheticSequence(1200, 5, seed=21)

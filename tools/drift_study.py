@@ -87,13 +87,13 @@ def host_runs(seq, k, m1, m2, max_iterations=1000):
     return rel, rel_lr, rel_gtX
 
 
-def device_run(seq, k, m1, m2, n_hyp=1000):
+def device_run(seq, k, m1, m2, n_hyp=1000, stereo_refine=False):
     import torch
     from slam_amd import pipeline
     fe = pipeline.FrontEnd(k, m1, m2)
     tb = pipeline.FrameTables.from_frames(seq.frames, torch.device("cuda", 0))
     ws = fe.prepare(tb, n_hyp=n_hyp)
-    fe.run_ransac(ws, 6)
+    fe.run_ransac(ws, 6, stereo_refine=stereo_refine)
     torch.cuda.synchronize()
     P = ws.P
     return list(ws.pose.cpu().numpy()[:P].reshape(P, 3, 4)), float(ws.ratio[:P].mean().item())
@@ -113,6 +113,9 @@ def main():
         gt = [seq.relative_pose(p, p + 1) for p in range(a.frames - 1)]
         dev, ratio = device_run(seq, k, m1, m2)
         out.append(dict(summarize(f"device RANSAC, noise {noise}", dev, gt, m1, seq.step), mean_inlier_ratio=ratio))
+        dev, ratio = device_run(seq, k, m1, m2, stereo_refine=True)
+        out.append(dict(summarize(f"device RANSAC, refinement on left+right residuals, noise {noise}", dev, gt, m1,
+                                  seq.step), mean_inlier_ratio=ratio))
         rel, rel_lr, rel_gtX = host_runs(seq, k, m1, m2)
         out.append(summarize(f"host solver (left-image refinement), noise {noise}", rel, gt, m1, seq.step))
         out.append(summarize(f"host solver + refinement on left+right residuals, noise {noise}", rel_lr, gt, m1, seq.step))
@@ -123,6 +126,9 @@ def main():
         gt = [seq.relative_pose(p, p + 1) for p in range(a.long_frames - 1)]
         dev, ratio = device_run(seq, k, m1, m2)
         out.append(dict(summarize("device RANSAC, noise 0.3, long", dev, gt, m1, seq.step), mean_inlier_ratio=ratio))
+        dev, ratio = device_run(seq, k, m1, m2, stereo_refine=True)
+        out.append(dict(summarize("device RANSAC, refinement on left+right residuals, noise 0.3, long", dev, gt, m1,
+                                  seq.step), mean_inlier_ratio=ratio))
     print(json.dumps(out, indent=1))
 
 

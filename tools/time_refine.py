@@ -41,6 +41,23 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         print(f"pairs={pairs} iterations<={its}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us", flush=True)
+    # the fused tail of the loop (supporters, refinement, supporters of the result): left-image cost, and with
+    # the right image's residuals added
+    for name, entry in (("slam_refine_winners", fe.lib.slam_refine_winners),
+                        ("slam_refine_winners_stereo", fe.lib.slam_refine_winners_stereo)):
+        def go():
+            _lib.check(entry(ws.hK, ws.hT, fe.pix_thresh, _p(c.X), _p(c.Y), _p(c.Z), _p(c.uL), _p(c.vL), _p(c.uR), _p(c.vR),
+                             ws.cap, _p(c.count), 0, _p(ws.best_Rt), ws.P, 30, _p(ws.ref_Rt), _p(ws.ref_ok),
+                             _p(ws.final_count), stream), name)
+        for _ in range(3):
+            go()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            go()
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"pairs={pairs} {name}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us", flush=True)
 
 
 if __name__ == "__main__":
