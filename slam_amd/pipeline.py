@@ -460,6 +460,26 @@ def capture(fe, ws, Rt=None):
     return graph
 
 
+def capture_ransac(fe, ws, seed, **kw):
+    """Record one `fe.run_ransac(ws, seed, **kw)` -- matching, triangulation, join and the whole
+    device-side RANSAC -- into a HIP graph.  None of its launches waits for the host (the slices
+    after the first are skipped on the device for the pairs the stopping rule has ended), so one
+    `graph.replay()` replaces about twenty launches: what a caller with one or a few frame pairs at a
+    time is bound by.  Buffers and the seed are baked in; feed new frames by writing into `ws.tb`."""
+    if not hasattr(ws, "samples"):
+        fe.prepare_ransac(ws)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fe.run_ransac(ws, seed, **kw)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        fe.run_ransac(ws, seed, **kw)
+    return graph
+
+
 def consensus_to_host(ws):
     """Copy the per-pair consensus tables back: list of dicts (rows [M,4], X [M,3], ...)."""
     c = ws.cons

@@ -236,6 +236,42 @@ def test_graph_replay_matches_plain_launches(device):
         Rt.copy_(torch.from_numpy(np.ascontiguousarray(Rt_host[:, ::-1])).to(device))
 
 
+def test_graph_replay_of_the_device_ransac(device):
+    """run_ransac recorded into a HIP graph: same poses, counts and inlier tables as plain launches, also
+    after other frames were written into the same tables, and with the stereo refinement option."""
+    k, m1, m2 = read_cameras()
+    seqs = [SyntheticSequence(700, 4, seed=s) for s in (5, 9)]
+    fe = pipeline.FrontEnd(k, m1, m2)
+    tb = pipeline.FrameTables.from_frames(seqs[0].frames, device)
+    names = ("pose", "ratio", "found", "iters", "best_count", "n_inl", "inl_rows", "inl_loc", "counts")
+    for kw in ({}, {"stereo_refine": True}):
+        ws = fe.prepare(tb, n_hyp=256)
+        graph = pipeline.capture_ransac(fe, ws, 6, **kw)
+        for seq in seqs:
+            other = pipeline.FrameTables.from_frames(seq.frames, device)
+            for name in ("descL", "descR", "xL", "yL", "xR", "yR"):
+                getattr(tb, name).copy_(getattr(other, name))
+            fe.run_ransac(ws, 6, **kw)
+            torch.cuda.synchronize()
+            plain = {n: getattr(ws, n).clone() for n in names}
+            for n in names:
+                getattr(ws, n).fill_(0)
+            graph.replay()
+            torch.cuda.synchronize()
+            n_i = int(ws.n_inl.sum())
+            assert n_i > 0 and bool(ws.found[:ws.P].all())
+            first = 128                                  # counts beyond the first slice exist only for pairs still running
+            for n in names:
+                a, b = plain[n], getattr(ws, n)
+                if n.startswith("inl_"):
+                    a, b = a[:n_i], b[:n_i]
+                if n == "counts":
+                    a, b = a[:, :first], b[:, :first]
+                assert torch.equal(a, b), (kw, n)
+            gt = np.stack([seq.relative_pose(p, p + 1) for p in range(ws.P)])
+            assert np.abs(ws.pose.cpu().numpy()[:ws.P].reshape(-1, 3, 4) - gt).max() < 0.05
+
+
 def test_winner_tables_match_the_mask_path(device):
     """slam_winner_tables (flags of the winner recomputed beside the compaction) against the
     longer route through the C ABI: one-hypothesis scoring with a supporter mask, prefix sum,
