@@ -152,7 +152,8 @@ void oracle_row_filter(const int32_t *idx, int idx_stride, int n,
  * right singular vector of the smallest singular value, dehomogenised.  The
  * reference takes it from LAPACK (np.linalg.svd); here it is found by a
  * one-sided Jacobi (Hestenes) iteration on the columns of A, which is what the
- * HIP kernel runs per lane.  The numpy twin (oracle/numpy_twin.py) keeps the
+ * HIP kernel runs per lane (sums as fma chains, every operation rounded once:
+ * the same bits on the CPU and on the GPU).  The numpy twin (oracle/numpy_twin.py) keeps the
  * LAPACK call and is the check on this restatement (agreement ~1e-12
  * relative; the contract is 1e-4).
  *
@@ -179,28 +180,30 @@ void oracle_dlt_point(const double *P, const double *Q, double x1, double y1,
         int rotated = 0;
         for (int p = 0; p < 3; ++p) {
             for (int q = p + 1; q < 4; ++q) {
-                double alpha = 0.0, beta = 0.0, gamma = 0.0;
-                for (int r = 0; r < 4; ++r) {
-                    alpha += a[r][p] * a[r][p];
-                    beta += a[r][q] * a[r][q];
-                    gamma += a[r][p] * a[r][q];
-                }
+                const double alpha = fma(a[3][p], a[3][p], fma(a[2][p], a[2][p], fma(a[1][p], a[1][p], a[0][p] * a[0][p])));
+                const double beta = fma(a[3][q], a[3][q], fma(a[2][q], a[2][q], fma(a[1][q], a[1][q], a[0][q] * a[0][q])));
+                const double gamma = fma(a[3][p], a[3][q], fma(a[2][p], a[2][q], fma(a[1][p], a[1][q], a[0][p] * a[0][q])));
                 if (gamma * gamma <= DLT_TOL2 * (alpha * beta))
                     continue;
                 rotated = 1;
-                double zeta = (beta - alpha) / (2.0 * gamma);
-                double tt = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                if (zeta < 0.0)
-                    tt = -tt;
-                double cs = 1.0 / sqrt(1.0 + tt * tt);
-                double sn = cs * tt;
-                for (int r = 0; r < 4; ++r) {
-                    double ap = a[r][p], aq = a[r][q];
-                    a[r][p] = cs * ap - sn * aq;
-                    a[r][q] = sn * ap + cs * aq;
-                    double vp = v[r][p], vq = v[r][q];
-                    v[r][p] = cs * vp - sn * vq;
-                    v[r][q] = sn * vp + cs * vq;
+                /* The Jacobi rotation with tan = g / D, d = beta - alpha, g = 2 gamma,
+                 * D = d + sign(d) * hypot(d, g) (the smaller root), written so that it
+                 * costs two square roots and one division:
+                 * (cs, sn) = (|D|, sign(D) * g) / hypot(D, g). */
+                const double d = beta - alpha, g = 2.0 * gamma;
+                const double gg = g * g;
+                const double r = sqrt(fma(d, d, gg));
+                const double D = d + copysign(r, d);
+                const double inv = 1.0 / sqrt(fma(D, D, gg));
+                const double cs = fabs(D) * inv;
+                const double sn = (D < 0.0 ? -g : g) * inv;
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const double ap = a[r4][p], aq = a[r4][q];
+                    a[r4][p] = fma(cs, ap, -(sn * aq));
+                    a[r4][q] = fma(sn, ap, cs * aq);
+                    const double vp = v[r4][p], vq = v[r4][q];
+                    v[r4][p] = fma(cs, vp, -(sn * vq));
+                    v[r4][q] = fma(sn, vp, cs * vq);
                 }
             }
         }
@@ -210,9 +213,7 @@ void oracle_dlt_point(const double *P, const double *Q, double x1, double y1,
     int jmin = 0;
     double nmin = 0.0;
     for (int c = 0; c < 4; ++c) {
-        double n2 = 0.0;
-        for (int r = 0; r < 4; ++r)
-            n2 += a[r][c] * a[r][c];
+        const double n2 = fma(a[3][c], a[3][c], fma(a[2][c], a[2][c], fma(a[1][c], a[1][c], a[0][c] * a[0][c])));
         if (c == 0 || n2 < nmin) {
             nmin = n2;
             jmin = c;

@@ -39,36 +39,37 @@ __device__ __forceinline__ void dlt_point(const Mat34 &P, const Mat34 &Q, double
         for (int c = 0; c < 4; ++c)
             v[r][c] = (r == c) ? 1.0 : 0.0;
 
+    // squared norm of column c / inner product of columns p and q, as fma chains
+    auto dot = [&](int p, int q) __attribute__((always_inline)) {
+        return __builtin_fma(a[3][p], a[3][q], __builtin_fma(a[2][p], a[2][q], __builtin_fma(a[1][p], a[1][q], a[0][p] * a[0][q])));
+    };
     for (int sweep = 0; sweep < DLT_MAX_SWEEPS; ++sweep) {
         bool rotated = false;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
             for (int q = p + 1; q < 4; ++q) {
-                double alpha = 0.0, beta = 0.0, gamma = 0.0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    alpha += a[r][p] * a[r][p];
-                    beta += a[r][q] * a[r][q];
-                    gamma += a[r][p] * a[r][q];
-                }
+                const double alpha = dot(p, p), beta = dot(q, q), gamma = dot(p, q);
                 if (gamma * gamma <= DLT_TOL2 * (alpha * beta))
                     continue;
                 rotated = true;
-                const double zeta = (beta - alpha) / (2.0 * gamma);
-                double tt = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                if (zeta < 0.0)
-                    tt = -tt;
-                const double cs = 1.0 / sqrt(1.0 + tt * tt);
-                const double sn = cs * tt;
+                // tan = g / D with d = beta - alpha, g = 2 gamma, D = d + sign(d) hypot(d, g) (the smaller
+                // root); (cs, sn) = (|D|, sign(D) g) / hypot(D, g): two square roots and one division
+                const double d = beta - alpha, g = 2.0 * gamma;
+                const double gg = g * g;
+                const double r = sqrt(__builtin_fma(d, d, gg));
+                const double D = d + __builtin_copysign(r, d);
+                const double inv = 1.0 / sqrt(__builtin_fma(D, D, gg));
+                const double cs = __builtin_fabs(D) * inv;
+                const double sn = (D < 0.0 ? -g : g) * inv;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double ap = a[r][p], aq = a[r][q];
-                    a[r][p] = cs * ap - sn * aq;
-                    a[r][q] = sn * ap + cs * aq;
-                    const double vp = v[r][p], vq = v[r][q];
-                    v[r][p] = cs * vp - sn * vq;
-                    v[r][q] = sn * vp + cs * vq;
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const double ap = a[r4][p], aq = a[r4][q];
+                    a[r4][p] = __builtin_fma(cs, ap, -(sn * aq));
+                    a[r4][q] = __builtin_fma(sn, ap, cs * aq);
+                    const double vp = v[r4][p], vq = v[r4][q];
+                    v[r4][p] = __builtin_fma(cs, vp, -(sn * vq));
+                    v[r4][q] = __builtin_fma(sn, vp, cs * vq);
                 }
             }
         }
@@ -78,10 +79,7 @@ __device__ __forceinline__ void dlt_point(const Mat34 &P, const Mat34 &Q, double
     double nmin = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        double n2 = 0.0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            n2 += a[r][c] * a[r][c];
+        const double n2 = dot(c, c);
         if (c == 0 || n2 < nmin) {
             nmin = n2;
             s0 = v[0][c];
