@@ -95,7 +95,7 @@ def loop_closure_pairs(n_frames, keyframe_stride=20, min_gap=30):
     return np.asarray(out, dtype=np.int64).reshape(-1, 2)
 
 
-def loop_closure_batched(frames, pairs, cameras=None, thresh=0.6, n_hyp=None, seed=6, device=None):
+def loop_closure_batched(frames, pairs, cameras=None, thresh=0.6, n_hyp=None, seed=6, device=None, stereo_refine=False):
     """Consensus matching of many keyframe pairs at once: what
     consensus_matching_of_general_two_frames (models/LoopClosure.py:112-139) does for one pair --
     stereo matching and triangulation of both keyframes, left-left 2-NN matching at ratio
@@ -116,7 +116,7 @@ def loop_closure_batched(frames, pairs, cameras=None, thresh=0.6, n_hyp=None, se
     fe = pipeline.FrontEnd(k, m1, m2, row_thresh=STEREO_ROW_THRESH, ratio_thresh=thresh, pix_thresh=PIXEL_THRESH)
     tb = pipeline.FrameTables.from_frames(frames, device)
     ws = fe.prepare(tb, n_hyp=n_hyp, pairs=pairs)
-    fe.run_ransac(ws, seed)
+    fe.run_ransac(ws, seed, stereo_refine=stereo_refine)     # (option: left + right residuals, see track_camera_device)
     P = ws.P
     # kept left-left matches per pair: segment sums of the ratio-test mask
     csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=ws.t_keep.device), ws.t_keep.to(torch.int64).cumsum(0)])
