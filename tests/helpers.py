@@ -63,3 +63,29 @@ def oracle_match(items, D, k):
     if not idxs:
         return np.zeros((0, 2), np.int32), np.zeros((0, 2), np.int32)
     return np.concatenate(idxs), np.concatenate(dists)
+
+
+def scipy_pnp_minimum(X, uv, k, start, uv_right=None, t_right=None):
+    """The minimiser of the reprojection error found by a solver that shares no code with this
+    repository: scipy.optimize.least_squares (MINPACK's Levenberg-Marquardt) over a rotation vector
+    and a translation, started from `start` [3,4].  The cost is the one cv2.solvePnP(
+    SOLVEPNP_ITERATIVE) minimises for the reference (left-image pixels, utils/utils.py:452); with
+    uv_right / t_right the right image's residuals are added.  Returns (pose [3,4], cost)."""
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation
+
+    X, uv = np.asarray(X, np.float64), np.asarray(uv, np.float64)
+    fx, fy, cx, cy = k[0, 0], k[1, 1], k[0, 2], k[1, 2]
+
+    def residuals(p):
+        Y = X @ Rotation.from_rotvec(p[:3]).as_matrix().T + p[3:]
+        r = [fx * Y[:, 0] / Y[:, 2] + cx - uv[:, 0], fy * Y[:, 1] / Y[:, 2] + cy - uv[:, 1]]
+        if uv_right is not None:
+            Yr = Y + np.asarray(t_right, np.float64)
+            r += [fx * Yr[:, 0] / Yr[:, 2] + cx - uv_right[:, 0], fy * Yr[:, 1] / Yr[:, 2] + cy - uv_right[:, 1]]
+        return np.concatenate(r)
+
+    p0 = np.concatenate([Rotation.from_matrix(start[:, :3]).as_rotvec(), start[:, 3]])
+    sol = least_squares(residuals, p0, method="lm", xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=2000)
+    pose = np.hstack([Rotation.from_rotvec(sol.x[:3]).as_matrix(), sol.x[3:, None]])
+    return pose, float((sol.fun ** 2).sum())

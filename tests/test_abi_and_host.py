@@ -223,6 +223,83 @@ def test_p3p_and_refinement_recover_known_poses():
     assert pnp.p3p_4pt(np.repeat(X[:1], 4, axis=0), uv[:4], k) is None  # degenerate sample
 
 
+def test_host_refinement_finds_the_minimum_an_independent_solver_finds():
+    """pnp.refine_pnp stands in for cv2.solvePnP(SOLVEPNP_ITERATIVE) (utils/utils.py:452), which cannot run
+    here.  What can be pinned without it: the minimum of that cost is a property of the data, so a
+    Levenberg-Marquardt that shares no code with this repository (MINPACK through scipy) must arrive at the same
+    pose from the same start -- with the left image's residuals alone and with both images'."""
+    from helpers import scipy_pnp_minimum
+    k, m1, m2 = read_cameras()
+    t_right = m2[:, 3]
+    rng = np.random.default_rng(12)
+    for trial in range(12):
+        n = int(rng.integers(6, 400))
+        R, t = rodrigues(rng.normal(size=3) * 0.05), rng.normal(size=3) * 0.5
+        X = np.stack([rng.uniform(-20, 20, n), rng.uniform(-3, 2, n), np.exp(rng.uniform(np.log(4), np.log(80), n))], axis=1)
+        Y = X @ R.T + t
+        uvL = np.stack([k[0, 0] * Y[:, 0] / Y[:, 2] + k[0, 2], k[1, 1] * Y[:, 1] / Y[:, 2] + k[1, 2]], axis=1)
+        Yr = Y + t_right
+        uvR = np.stack([k[0, 0] * Yr[:, 0] / Yr[:, 2] + k[0, 2], k[1, 1] * Yr[:, 1] / Yr[:, 2] + k[1, 2]], axis=1)
+        uvL, uvR = uvL + rng.normal(0, 0.4, uvL.shape), uvR + rng.normal(0, 0.4, uvR.shape)
+        start = np.hstack([rodrigues(rng.normal(size=3) * 5e-3) @ R, (t + rng.normal(size=3) * 0.05)[:, None]])
+        for right in (False, True):
+            kw = dict(points_2d_right=uvR, t_right=t_right) if right else {}
+            mine = pnp.refine_pnp(X, uvL, k, start, **kw)
+            theirs, cost = scipy_pnp_minimum(X, uvL, k, start, uvR if right else None, t_right if right else None)
+            assert np.abs(mine - theirs).max() < 2e-7, (trial, right)
+            Ym = X @ mine[:, :3].T + mine[:, 3]
+            r = [k[0, 0] * Ym[:, 0] / Ym[:, 2] + k[0, 2] - uvL[:, 0], k[1, 1] * Ym[:, 1] / Ym[:, 2] + k[1, 2] - uvL[:, 1]]
+            if right:
+                Yq = Ym + t_right
+                r += [k[0, 0] * Yq[:, 0] / Yq[:, 2] + k[0, 2] - uvR[:, 0], k[1, 1] * Yq[:, 1] / Yq[:, 2] + k[1, 2] - uvR[:, 1]]
+            assert abs(float((np.concatenate(r) ** 2).sum()) - cost) <= 1e-9 * cost
+
+
+def test_p3p_branch_is_the_best_one_a_multistart_search_finds():
+    """pnp.p3p_4pt stands in for cv2.solvePnP(flags=SOLVEPNP_AP3P) on four points (utils/utils.py:428,481-492):
+    every pose that reprojects the first three points exactly is a candidate, the fourth point chooses.  Checked
+    against a search that shares nothing with the quartic solver: scipy's least squares from many random starts
+    collects poses with zero residual on the three points and all depths positive; none of them may fit the
+    fourth point better than the pose returned."""
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation
+    k, m1, m2 = read_cameras()
+    fx, fy, cx, cy = k[0, 0], k[1, 1], k[0, 2], k[1, 2]
+    rng = np.random.default_rng(21)
+
+    def project(p, X):
+        Y = X @ Rotation.from_rotvec(p[:3]).as_matrix().T + p[3:]
+        return np.stack([fx * Y[:, 0] / Y[:, 2] + cx, fy * Y[:, 1] / Y[:, 2] + cy], axis=1), Y[:, 2]
+
+    checked = 0
+    for trial in range(12):
+        R, t = rodrigues(rng.normal(size=3) * 0.05), np.array([0.05, -0.02, -0.8]) + rng.normal(size=3) * 0.05
+        X = np.stack([rng.uniform(-15, 15, 4), rng.uniform(-3, 2, 4), np.exp(rng.uniform(np.log(5), np.log(60), 4))], axis=1)
+        Y = X @ R.T + t
+        uv = np.stack([fx * Y[:, 0] / Y[:, 2] + cx, fy * Y[:, 1] / Y[:, 2] + cy], axis=1) + rng.normal(0, 0.3, (4, 2))
+        mine = pnp.p3p_4pt(X, uv, k)
+        if mine is None:
+            continue
+        Ym = X @ mine[:, :3].T + mine[:, 3]
+        pm = np.stack([fx * Ym[:, 0] / Ym[:, 2] + cx, fy * Ym[:, 1] / Ym[:, 2] + cy], axis=1)
+        assert np.abs(pm[:3] - uv[:3]).max() < 1e-6
+        my_err = float(np.linalg.norm(pm[3] - uv[3]))
+        found = []
+        truth = np.concatenate([Rotation.from_matrix(R).as_rotvec(), t])
+        starts = [truth] + [np.concatenate([rng.normal(size=3) * s, t + rng.normal(size=3) * 10 * s])
+                            for s in (0.05, 0.3, 1.0) for _ in range(14)]
+        for p0 in starts:
+            sol = least_squares(lambda p: (project(p, X[:3])[0] - uv[:3]).ravel(), p0, method="lm", xtol=1e-14, ftol=1e-14,
+                                gtol=1e-14, max_nfev=400)
+            pr, depth = project(sol.x, X)
+            if np.abs(pr[:3] - uv[:3]).max() < 1e-7 and (depth > 0).all():
+                found.append(float(np.linalg.norm(pr[3] - uv[3])))
+        assert found, trial                                  # the start at the true pose converges at least
+        assert my_err <= min(found) + 1e-5, (trial, my_err, sorted(found)[:3])
+        checked += 1
+    assert checked >= 8
+
+
 def test_synthetic_sequence_shape_and_reproducibility():
     a = SyntheticSequence(300, 3)
     b = SyntheticSequence(300, 3)

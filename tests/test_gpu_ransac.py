@@ -156,6 +156,10 @@ def test_refinement_matches_the_host_solver(device):
     got = Rt.cpu().numpy()[0].reshape(3, 4)
     want = pnp.refine_pnp(X[mask_bits], uv[mask_bits].astype(np.float64), k, start)
     assert np.abs(got - want).max() < 1e-7
+    # and the minimum a solver from outside this repository finds (MINPACK's Levenberg-Marquardt through scipy)
+    from helpers import scipy_pnp_minimum
+    theirs, _ = scipy_pnp_minimum(X[mask_bits], uv[mask_bits].astype(np.float64), k, start)
+    assert np.abs(got - theirs).max() < 2e-7
     assert np.abs(got - pose).max() < 5e-3                    # and both sit at the noisy optimum near the truth
     assert np.abs(got[:, :3] @ got[:, :3].T - np.eye(3)).max() < 1e-12
     # fewer than three supporters: the start pose comes back, ok = 0
@@ -215,6 +219,7 @@ def test_stereo_refinement_matches_the_host_solver(device):
     against pnp.refine_pnp with the right image's keypoints on the same supporters: same pose to
     solver tolerance, ref_count = the supporters of the pose returned.  Set sizes on both sides of
     what a thread keeps in registers."""
+    from helpers import scipy_pnp_minimum
     k, m1, m2 = read_cameras()
     t_right = m2[:, 3]
     rng = np.random.default_rng(23)
@@ -257,6 +262,10 @@ def test_stereo_refinement_matches_the_host_solver(device):
         want = pnp.refine_pnp(X[s, :n][sup], uvL[s, :n][sup].astype(np.float64), k, start[s].reshape(3, 4),
                               points_2d_right=uvR[s, :n][sup].astype(np.float64), t_right=t_right)
         assert np.abs(got[s] - want).max() < 1e-7, s
+        if n <= 1537:                                           # (the independent solver: MINPACK through scipy)
+            theirs, _ = scipy_pnp_minimum(X[s, :n][sup], uvL[s, :n][sup].astype(np.float64), k, start[s].reshape(3, 4),
+                                          uvR[s, :n][sup].astype(np.float64), t_right)
+            assert np.abs(got[s] - theirs).max() < 2e-7, s
         assert np.abs(got[s][:, :3] @ got[s][:, :3].T - np.eye(3)).max() < 1e-12
         assert np.abs(got[s] - truth[s]).max() < 5e-3
         assert np.abs(got[s] - left[s]).max() > 1e-9            # a different cost, a (slightly) different optimum
