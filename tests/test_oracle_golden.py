@@ -33,6 +33,29 @@ def test_knn_padded_rows_and_threads():
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
+def test_knn_agrees_with_an_independent_distance_routine():
+    """Distances and order of the C oracle's k-NN against scipy's cdist (bit-unpacked Hamming, Euclidean) and a
+    stable sort: smallest distance first, the lower train index on equal distances (cv2.BFMatcher's scan order)."""
+    from scipy.spatial.distance import cdist
+    rng = np.random.default_rng(77)
+    for D in (32, 61, 64):
+        q = rng.integers(0, 256, (57, D), dtype=np.uint8)
+        t = np.concatenate([q[:9], rng.integers(0, 256, (140, D), dtype=np.uint8), q[:9]])      # exact duplicates: ties
+        t[20:40] &= 0x0F                                                                          # and a dense cluster
+        full = np.rint(cdist(np.unpackbits(q, axis=1), np.unpackbits(t, axis=1), "hamming") * 8 * D).astype(np.int64)
+        order = np.argsort(full, axis=1, kind="stable")[:, :2]
+        idx, dist = oracle.hamming_knn(q, t, 2)
+        assert np.array_equal(idx, order) and np.array_equal(dist, np.take_along_axis(full, order, axis=1))
+    # SIFT-like descriptors: integer-valued floats, squared distances exact in fp32
+    q = rng.integers(0, 256, (40, 128)).astype(np.float32)
+    t = np.concatenate([q[:5], rng.integers(0, 256, (90, 128)).astype(np.float32), q[:5]])
+    sq = np.rint(cdist(q.astype(np.float64), t.astype(np.float64), "sqeuclidean")).astype(np.int64)
+    order = np.argsort(sq, axis=1, kind="stable")[:, :2]
+    idx, dist = oracle.l2_knn(q, t, 2)
+    assert np.array_equal(idx, order)
+    assert np.array_equal(dist, np.sqrt(np.take_along_axis(sq, order, axis=1).astype(np.float32)))
+
+
 def test_ratio_filter_golden_grid():
     thrs = GOLD["ratio_thr"]
     grid = np.unpackbits(GOLD["ratio_grid"])[:len(thrs) * 489 * 489].reshape(len(thrs), 489, 489).astype(bool)
