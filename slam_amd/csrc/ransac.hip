@@ -451,13 +451,24 @@ struct RefineArgs {
 __device__ __forceinline__ void exp_so3(const double *w, double *E)
 {
     const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
-    const double th = sqrt(th2);
-    double A = 1.0, B = 0.5;
-    if (th >= 1e-12) {
+    double A, B;
+    if (th2 < 0.0625) {
+        // A = sin(th)/th and B = (1 - cos th)/th^2 as series in th^2 (an LM step is a small rotation;
+        // below th = 0.25 ten terms leave less than 1e-17)
+        A = 1.0;
+        B = 0.5;
+        double ta = 1.0, tb = 0.5;
+#pragma unroll
+        for (int n = 1; n <= 9; ++n) {
+            ta *= -th2 / (double)((2 * n) * (2 * n + 1));
+            tb *= -th2 / (double)((2 * n + 1) * (2 * n + 2));
+            A += ta;
+            B += tb;
+        }
+    } else {
+        const double th = sqrt(th2);
         A = sin(th) / th;
         B = (1.0 - cos(th)) / th2;
-    } else {
-        B = 0.0;   // first-order form below the switch, as the host solver
     }
     const double K[9] = {0.0, -w[2], w[1], w[2], 0.0, -w[0], -w[1], w[0], 0.0};
 #pragma unroll
@@ -488,6 +499,7 @@ __device__ __forceinline__ double row_peer(double v)
 __device__ __forceinline__ bool solve6(double (&M)[6][6], double (&rhs)[6], double (&x)[6])
 {
     bool ok = true;
+    double inv[6];   // one division per pivot: the thread that solves runs alone, every division is ~30 dependent instructions
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
         int piv = c;
@@ -512,13 +524,14 @@ __device__ __forceinline__ bool solve6(double (&M)[6][6], double (&rhs)[6], doub
             rhs[c] = sw ? dn : up;
             rhs[r] = sw ? up : dn;
         }
+        inv[c] = 1.0 / M[c][c];
 #pragma unroll
         for (int r = c + 1; r < 6; ++r) {
-            const double f = M[r][c] / M[c][c];
+            const double f = M[r][c] * inv[c];
 #pragma unroll
-            for (int k = c; k < 6; ++k)
-                M[r][k] -= f * M[c][k];
-            rhs[r] -= f * rhs[c];
+            for (int k = c + 1; k < 6; ++k)   // (column c itself is not read again)
+                M[r][k] = __builtin_fma(-f, M[c][k], M[r][k]);
+            rhs[r] = __builtin_fma(-f, rhs[c], rhs[r]);
         }
     }
 #pragma unroll
@@ -526,8 +539,8 @@ __device__ __forceinline__ bool solve6(double (&M)[6][6], double (&rhs)[6], doub
         double s = rhs[r];
 #pragma unroll
         for (int k = r + 1; k < 6; ++k)
-            s -= M[r][k] * x[k];
-        x[r] = s / M[r][r];
+            s = __builtin_fma(-M[r][k], x[k], s);
+        x[r] = s * inv[r];
     }
     return ok;
 }
@@ -617,18 +630,27 @@ __global__ void __launch_bounds__(256, 2) refine_kernel(const RefineArgs a)
             const double r1 = a.fy * z1 * iz + a.cy - v;
             const double du0 = a.fx * iz, du2 = -a.fx * z0 * iz * iz;
             const double dv1 = a.fy * iz, dv2 = -a.fy * z1 * iz * iz;
+            // the u row has no entry for t_y (column 4), the v row none for t_x (column 3)
             const double Ju[6] = {-(-du2 * y1), -(-du0 * y2 + du2 * y0), -(du0 * y1), du0, 0.0, du2};
             const double Jv[6] = {-(dv1 * y2 - dv2 * y1), -(dv2 * y0), -(-dv1 * y0), 0.0, dv1, dv2};
             int k = 0;
 #pragma unroll
             for (int p = 0; p < 6; ++p)
 #pragma unroll
-                for (int q = p; q < 6; ++q)
-                    acc[k++] += Ju[p] * Ju[q] + Jv[p] * Jv[q];
+                for (int q = p; q < 6; ++q, ++k) {
+                    if (p != 4 && q != 4)
+                        acc[k] = __builtin_fma(Ju[p], Ju[q], acc[k]);
+                    if (p != 3 && q != 3)
+                        acc[k] = __builtin_fma(Jv[p], Jv[q], acc[k]);
+                }
 #pragma unroll
-            for (int p = 0; p < 6; ++p)
-                acc[21 + p] += Ju[p] * r0 + Jv[p] * r1;
-            acc[27] += r0 * r0 + r1 * r1;
+            for (int p = 0; p < 6; ++p) {
+                if (p != 4)
+                    acc[21 + p] = __builtin_fma(Ju[p], r0, acc[21 + p]);
+                if (p != 3)
+                    acc[21 + p] = __builtin_fma(Jv[p], r1, acc[21 + p]);
+            }
+            acc[27] = __builtin_fma(r0, r0, __builtin_fma(r1, r1, acc[27]));
         };
         auto add_point = [&](int i, double X, double Y, double Z, float u, float v) {
             const double y0 = R[0] * X + R[1] * Y + R[2] * Z + R[3];
@@ -723,6 +745,13 @@ __global__ void __launch_bounds__(256, 2) refine_kernel(const RefineArgs a)
                         for (int j = 0; j < 3; ++j)
                             cand[4 * i + j] = E[3 * i] * pose[j] + E[3 * i + 1] * pose[4 + j] + E[3 * i + 2] * pose[8 + j];
                         cand[4 * i + 3] = E[3 * i] * pose[3] + E[3 * i + 1] * pose[7] + E[3 * i + 2] * pose[11] + step[3 + i];
+                    }
+                    // A step this small is the last one that matters: what would follow it is smaller by the
+                    // damping factor (below 1e-4 by now) -- take it without paying an evaluation to confirm it.
+                    if (wmax + dmax / (1.0 + tmax) < 1e-7) {
+                        for (int k = 0; k < 12; ++k)
+                            pose[k] = cand[k];
+                        state = 1;
                     }
                 }
             }
