@@ -178,7 +178,7 @@ int slam_row_filter(const float *y1_dev, const float *y2_dev, int n, double thr,
  * x1,y1,x2,y2: dev float32 [n] (left / right pixel coordinates).
  * X,Y,Z: dev float64 [n]; valid: dev u8 [n] = !(Z <= 0 || x1 < x2) (:326-327).
  * The null vector of the 4x4 system is found by a one-sided Jacobi SVD in
- * fp64 (agrees with LAPACK to ~1e-12 relative on KITTI geometry).
+ * fp64 (agrees with LAPACK to ~1e-10 relative on KITTI geometry).
  */
 int slam_triangulate_dlt(const double *P_host, const double *Q_host,
                          const float *x1_dev, const float *y1_dev,

@@ -154,7 +154,7 @@ void oracle_row_filter(const int32_t *idx, int idx_stride, int n,
  * one-sided Jacobi (Hestenes) iteration on the columns of A, which is what the
  * HIP kernel runs per lane (sums as fma chains, every operation rounded once:
  * the same bits on the CPU and on the GPU).  The numpy twin (oracle/numpy_twin.py) keeps the
- * LAPACK call and is the check on this restatement (agreement ~1e-12
+ * LAPACK call and is the check on this restatement (agreement ~1e-10
  * relative; the contract is 1e-4).
  *
  * valid[i] = !(Z <= 0 || x1 < x2)   (utils/utils.py:326-327).
