@@ -495,12 +495,13 @@ def main():
 
     graph = try_capture(ws)
     overlap = os.environ.get("SLAM_BENCH_OVERLAP", "1") != "0"
-    # Batches in flight (SLAM_BENCH_STREAMS, default 2): each has its own workspace, graph and launch
+    # Batches in flight (SLAM_BENCH_STREAMS, default 4; measured 1: 3.77, 2: 3.57, 3: 3.565, 4: 3.54, 6: 3.54 ms
+    # per step): each has its own workspace, graph and launch
     # stream, and the steps take turns.  The small latency-bound kernels and the tails of one batch
     # then run under the large kernels of the other; with more than one rank the gather of step i
     # (side stream, RCCL) also overlaps the kernels of step i+1.  A workspace is reused only after
     # its previous step -- and its gather -- has finished.
-    n_lanes = max(1, int(os.environ.get("SLAM_BENCH_STREAMS", "2")))
+    n_lanes = max(1, int(os.environ.get("SLAM_BENCH_STREAMS", "4")))
     if multi and not overlap:
         n_lanes = 1
     lanes = []
