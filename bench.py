@@ -605,9 +605,35 @@ def main():
         ransac_turns(20)
         torch.cuda.synchronize()
         ms2 = (time.perf_counter() - t0r) / 20 * 1e3
+        # and four, each recorded into a HIP graph (one host call per step instead of about twenty)
+        ms4 = None
+        try:
+            ws4 = [ws_r, ws_r2] + [fe.prepare(tb, n_hyp=Hr) for _ in range(2)]
+            gl = []
+            for w in ws4:
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st):
+                    gl.append((pipeline.capture_ransac(fe, w, 6), st))
+            def graph_turns(n):
+                for i in range(n):
+                    g, st = gl[i & 3]
+                    with torch.cuda.stream(st):
+                        g.replay()
+            graph_turns(4)
+            torch.cuda.synchronize()
+            t0r = time.perf_counter()
+            graph_turns(40)
+            torch.cuda.synchronize()
+            ms4 = (time.perf_counter() - t0r) / 40 * 1e3
+            del gl, ws4
+        except Exception as exc:                      # the plain-launch numbers stand on their own
+            print(f"[bench] device_ransac graph lanes failed ({exc})", file=sys.stderr)
+            torch.cuda.synchronize()
         del ws_r2
         ransac_info = {"hypotheses_per_pair": Hr, "ms_per_step": ms, "frame_pairs_per_s": P / (ms * 1e-3),
                        "two_batches_in_flight": {"ms_per_step": ms2, "frame_pairs_per_s": P / (ms2 * 1e-3)},
+                       "four_graphs_in_flight": ({"ms_per_step": ms4, "frame_pairs_per_s": P / (ms4 * 1e-3)}
+                                                 if ms4 is not None else None),
                        "mean_iterations_until_stop": float(ws_r.iters[:P].float().mean().item()),
                        "mean_inlier_ratio": float(ws_r.ratio[:P].mean().item()),
                        "note": "whole front-end incl. device-side minimal samples, P3P, stopping rule and LM "
