@@ -581,15 +581,16 @@ def main():
         Hr = 1000                                   # the VO loop's max_iterations (utils/utils.py:275)
         ws_r = fe.prepare(tb, n_hyp=Hr)
         fe.prepare_ransac(ws_r)
-        fe.run_ransac(ws_r, 6)
+        for _ in range(3):
+            fe.run_ransac(ws_r, 6)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(5):
+        for _ in range(20):
             fe.run_ransac(ws_r, 6)
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 5
+        ms = e0.elapsed_time(e1) / 20
         # the same with two batches in flight (plain launches on two streams, taking turns)
         ws_r2 = fe.prepare(tb, n_hyp=Hr)
         fe.prepare_ransac(ws_r2)
