@@ -60,3 +60,14 @@ def test_c_client_matches_the_oracle(tmp_path, n_kp, desc_bytes):
         assert np.array_equal(got[name][kept], want[kept]), name          # bit for bit
         assert np.isnan(got[name][~kept]).all()
     assert f"matches kept {int(kept.sum())}," in text
+
+
+def test_c_client_with_an_empty_right_image(tmp_path):
+    """No right keypoints at all: every left row reports no neighbour, nothing is kept, nothing triangulated."""
+    k, m1, m2 = read_cameras()
+    fr = SyntheticSequence(50, 1, seed=9).frames[0]
+    got, text = _run(tmp_path, fr.descL, fr.descR[:0], fr.kpL, fr.kpR[:0], k @ m1, k @ m2, 2.0)
+    assert (got["idx"] == -1).all() and (got["dist"] == np.iinfo(np.int32).max).all()
+    assert not got["keep"].any() and not got["valid"].any() and (got["map"] == -1).all()
+    assert np.isnan(got["X"]).all() and np.isnan(got["Y"]).all() and np.isnan(got["Z"]).all()
+    assert "matches kept 0," in text
